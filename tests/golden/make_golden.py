@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Regenerates every golden vector under tests/golden/ from the UNMODIFIED reference.
+
+Needs oracle/_ref (built by `make -C oracle ref` in the container that has
+/root/reference).  Everything written here is DATA: synthetic inputs plus the outputs the
+compiled reference produced for them (strict build: -ffp-contract=off).
+
+  tables.bin            fmath expd/log tables + probe values      (ref_harness tables)
+  corpus.fa/.racc       Raccess acc/cond for an edge-case corpus   (ref_harness raccess)
+  c1_{q,db}.fa          BASELINE config 1 inputs (32x200 vs 32x200, seeds 2/1)
+  c1db.*.gz             the reference `db` output for c1_db.fa (defaults)
+  c1_ris_s{0,1}.out     reference `ris` output (-s 0 / -s 1), body lines sorted, Id stripped
+  c1.stg.gz             per-stage hit dumps for C1                 (ref_harness stages)
+  mix_*.fa, mixdb.*.gz, mix_ris_s{0,1}.out, mix.stg.gz
+                        mixed-length case: N / lowercase, 3 DB pages (-c 10)
+  c1_q.sa               encoder + suffix array goldens             (ref_harness sa)
+"""
+import gzip
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_synthetic  # noqa: E402
+
+
+def run(*cmd, cwd=None):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    subprocess.run(list(cmd), check=True, cwd=cwd, env=env)
+
+
+def gz(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
+        shutil.copyfileobj(f, g)
+
+
+def body_sorted(path):
+    with open(path) as f:
+        lines = f.read().splitlines()
+    head, body = lines[:3], lines[3:]
+    body = sorted(l.split(",", 1)[1] for l in body)
+    return head, body
+
+
+def corpus():
+    rng = random.Random(7)
+    recs = []
+    for L in range(1, 11):
+        recs.append((f"len{L}", "".join(rng.choice("ACGU") for _ in range(L))))
+    recs.append(("len60", "".join(rng.choice("ACGU") for _ in range(60))))
+    recs.append(("len71", "".join(rng.choice("ACGU") for _ in range(71))))
+    recs.append(("len72", "".join(rng.choice("ACGU") for _ in range(72))))
+    recs.append(("len200", "".join(rng.choice("ACGU") for _ in range(200))))
+    recs.append(("len330", "".join(rng.choice("ACGU") for _ in range(330))))
+    recs.append(("len1000", "".join(rng.choice("ACGU") for _ in range(1000))))
+    recs.append(("gc2000", "".join(rng.choice("GGGCCCAU") for _ in range(2000))))
+    recs.append(("len2700", "".join(rng.choice("ACGU") for _ in range(2700))))
+    recs.append(("polyA", "A" * 90))
+    recs.append(("polyGC", "GC" * 60))
+    recs.append(("hairpins", ("GGGGGCCAAAAGGCCCCC" + "AUAU") * 8))
+    s = list("".join(rng.choice("ACGU") for _ in range(300)))
+    for k in range(100, 120):
+        s[k] = "N"
+    for k in range(200, 240):
+        s[k] = s[k].lower()
+    recs.append(("withN_lower", "".join(s)))
+    recs.append(("dna_T", "".join(rng.choice("ACGT") for _ in range(150))))
+    recs.append(("allN", "N" * 40))
+    return recs
+
+
+def mix_inputs():
+    rng = random.Random(11)
+    db = []
+    for i in range(24):
+        L = rng.randint(50, 400)
+        s = list("".join(rng.choice("ACGU") for _ in range(L)))
+        if i % 5 == 0:
+            a = rng.randint(0, L - 12)
+            for k in range(a, a + 10):
+                s[k] = "N"
+        if i % 7 == 0:
+            a = rng.randint(0, L - 20)
+            for k in range(a, a + 18):
+                s[k] = s[k].lower()
+        db.append((f"mdb{i}", "".join(s)))
+    q = []
+    for i in range(6):
+        L = rng.randint(100, 600)
+        s = list("".join(rng.choice("ACGU") for _ in range(L)))
+        if i == 2:
+            for k in range(40, 46):
+                s[k] = "N"
+        q.append((f"mq{i}", "".join(s)))
+    # one query that is the reverse complement of a DB stretch: long perfect duplex
+    comp = {"A": "U", "C": "G", "G": "C", "U": "A"}
+    src = db[3][1][20:90].upper().replace("N", "A")
+    q.append(("mq_rc", "ACGUACGUAC" + "".join(comp[c] for c in reversed(src)) + "UUGACCA"))
+    return q, db
+
+
+def main():
+    assert os.path.exists(os.path.join(REF, "ref_harness")), "run `make -C oracle ref` first"
+    strict = os.path.join(REF, "pRIblast.strict")
+    harness = os.path.join(REF, "ref_harness")
+    tmp = tempfile.mkdtemp(prefix="golden_")
+
+    run(harness, "tables", os.path.join(HERE, "tables.bin"))
+
+    gen_synthetic.write_fasta(os.path.join(HERE, "corpus.fa"), corpus())
+    run(harness, "raccess", os.path.join(HERE, "corpus.fa"), "70", "5", os.path.join(HERE, "corpus.racc"))
+
+    # ---- config 1 ----
+    gen_synthetic.write_fasta(os.path.join(HERE, "c1_db.fa"), gen_synthetic.gen(32, 200, 1, "db"))
+    gen_synthetic.write_fasta(os.path.join(HERE, "c1_q.fa"), gen_synthetic.gen(32, 200, 2, "q"))
+    # a second (W, delta) so the band geometry is not hard-wired to the defaults
+    run(harness, "raccess", os.path.join(HERE, "c1_q.fa"), "40", "7", os.path.join(HERE, "c1_q_w40d7.racc"))
+    run(harness, "sa", os.path.join(HERE, "c1_q.fa"), "0", os.path.join(HERE, "c1_q.sa"))
+    cases = [("c1", "c1_q.fa", "c1_db.fa", []), ("mix", "mix_q.fa", "mix_db.fa", ["-c", "10"])]
+    mq, mdb = mix_inputs()
+    gen_synthetic.write_fasta(os.path.join(HERE, "mix_q.fa"), mq)
+    gen_synthetic.write_fasta(os.path.join(HERE, "mix_db.fa"), mdb)
+    for tag, qfa, dbfa, dbopts in cases:
+        dbp = os.path.join(tmp, tag + "db")
+        run(strict, "db", "-i", os.path.join(HERE, dbfa), "-o", dbp, *dbopts, cwd=tmp)
+        for ext in ("bas", "seq", "acc", "nam", "ind"):
+            gz(f"{dbp}.{ext}", os.path.join(HERE, f"{tag}db.{ext}.gz"))
+        for style in (0, 1):
+            out = os.path.join(tmp, f"{tag}_s{style}.out")
+            run(strict, "ris", "-i", os.path.join(HERE, qfa), "-o", out, "-d", dbp, "-s", str(style), cwd=tmp)
+            head, body = body_sorted(out)
+            with open(os.path.join(HERE, f"{tag}_ris_s{style}.out"), "w") as f:
+                f.write("\n".join(head[:1] + head[2:] + body) + "\n")
+        stg = os.path.join(tmp, tag + ".stg")
+        run(harness, "stages", os.path.join(HERE, qfa), dbp, stg)
+        gz(stg, os.path.join(HERE, tag + ".stg.gz"))
+    shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    main()
