@@ -1,0 +1,147 @@
+/* include/priblast_hip.h -- C ABI of the MI355X-native `ris` hot path (libpriblast_hip.so).
+ *
+ * The reference (UDC-GAC/pRIblast) has no FFI / plugin interface; its only internal seam is
+ * the five private per-query stage wrappers of RnaInteractionSearch
+ * (rna_interaction_search.hpp:51-79, called from rna_interaction_search.cpp:171-197):
+ *
+ *   CalculateAccessibility  rna_interaction_search.cpp:242-250  -> prb_qbatch_accessibility
+ *   ConstructSuffixArray    rna_interaction_search.cpp:252-262  -> prb_qbatch_create (host)
+ *   SearchSeed              rna_interaction_search.cpp:264-283  -> prb_search_page (stage 1)
+ *   ExtendWithoutGap        rna_interaction_search.cpp:285-300  -> prb_search_page (stage 2)
+ *   ExtendWithGap           rna_interaction_search.cpp:302-320  -> prb_search_page (stage 3)
+ *   DbReader::LoadDatabases db_reader.cpp:29-59                 -> prb_db_open
+ *   Raccess::Run(seq, idx)  raccess.cpp:34-40 (db side)         -> prb_accessibility
+ *
+ * The entry points below are the batched form of that seam: plain pointers and sizes,
+ * opaque handles, integer status returns (0 = ok, <0 = error; prb_last_error() gives the
+ * text), no exceptions and no C++/torch types across the boundary.  All device work runs
+ * on the handle's own HIP stream; the library never falls back to the CPU - if no HIP
+ * device can be initialised prb_ctx_create fails.
+ *
+ * Layouts follow the reference: accessibility arrays are `float[L]` per sequence
+ * (raccess.cpp:484-528), encoded queries are `uint8_t[L+1]` (encoder.cpp:38-44), suffix
+ * arrays `int32_t[L+1]`, database files are read unchanged (.bas/.seq/.acc/.nam/.ind).
+ */
+#ifndef PRIBLAST_HIP_H
+#define PRIBLAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRB_OK 0
+#define PRB_ERR_ARG (-1)
+#define PRB_ERR_IO (-2)
+#define PRB_ERR_HIP (-3)
+#define PRB_ERR_NOMEM (-4)
+#define PRB_ERR_STATE (-5)
+
+typedef struct prb_ctx prb_ctx;       /* one GPU: stream, parameter tables, workspaces */
+typedef struct prb_db prb_db;         /* database pages resident in HBM */
+typedef struct prb_qbatch prb_qbatch; /* a batch of queries: enc + SA + accessibilities */
+typedef struct prb_hitset prb_hitset; /* result of prb_search_page, host side */
+
+/* `ris` options, defaults of rna_interaction_search_parameters.hpp:54-62 */
+typedef struct prb_ris_opts {
+  int32_t max_seed_length;    /* -l 20 */
+  double hybrid_threshold;    /* -e -6.0 */
+  double interaction_threshold; /* -f -4.0 */
+  double final_threshold;     /* -g -8.0 */
+  int32_t drop_out_wo_gap;    /* -y 5  */
+  int32_t drop_out_w_gap;     /* -x 16 */
+  int32_t min_helix_length;   /* -m 3  */
+  int32_t output_style;       /* -s 0  */
+} prb_ris_opts;
+
+/* POD form of hit.hpp:38-118 (`Hit`) */
+typedef struct prb_hit {
+  int32_t q_sp, db_sp;          /* start in the query / in the page's reversed db text */
+  int32_t q_len, db_len;
+  int32_t db_id, db_id_start;   /* sequence index in the page, forward start in it */
+  double e_acc, e_hyb, e_tot;   /* kcal/mol */
+  int32_t query;                /* index in the batch */
+  int32_t bp_count;             /* base pairs in prb_hitset_basepairs, at bp_offset */
+  int64_t bp_offset;
+} prb_hit;
+
+const char *prb_last_error(void);
+const char *prb_version(void);
+void prb_ris_opts_default(prb_ris_opts *o);
+
+/* ---- context ---- */
+/* param_file: nearest-neighbour parameter data (priblast_amd/params/rna_andronescu2007.par);
+ * NULL = the file next to the library. */
+int prb_ctx_create(int device, const char *param_file, prb_ctx **out);
+void prb_ctx_destroy(prb_ctx *ctx);
+int prb_ctx_synchronize(prb_ctx *ctx);
+/* device time (ms, HIP events on the library's stream) of the named stage since the last
+ * reset: "raccess", "seed", "ungapped", "gapped", "filter"; also launch counts. */
+int prb_ctx_stage_ms(prb_ctx *ctx, const char *stage, double *ms, int64_t *launches);
+void prb_ctx_reset_timers(prb_ctx *ctx);
+
+/* ---- stage 1: accessibility (Raccess), batched over sequences ----
+ * seqs: concatenated characters, sequence i = seqs[offsets[i] .. offsets[i+1]);
+ * acc/cond: concatenated float outputs with the same offsets (L floats per sequence,
+ * entries the reference leaves untouched are 0), host memory. */
+int prb_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_t *offsets,
+                      int32_t maximal_span, int32_t min_accessible_length, float *acc, float *cond);
+
+/* diagnostics: runs Raccess for ONE sequence and returns the DP tables in the reference's
+ * own layout (raccess.hpp:89-103): alpha_outer/beta_outer hold L+1 doubles; tables[0..5] =
+ * Alpha_{stem,stemend,multi,multibif,multi1,multi2}, tables[6..11] = Beta_ same order, each
+ * (L+1)*(W+2) doubles, row-major [i][j-i]; NULL entries are skipped. */
+int prb_accessibility_tables(prb_ctx *ctx, const char *seq, int32_t len, int32_t maximal_span,
+                             int32_t min_accessible_length, float *acc, float *cond,
+                             double *alpha_outer, double *beta_outer, double *const tables[12]);
+
+/* ---- host helpers that are part of the seam (stage 2: encode + suffix array) ---- */
+int prb_encode_query(const char *seq, int32_t len, int32_t repeat_flag, uint8_t *enc /* len+1 */);
+int prb_suffix_array(const uint8_t *text, int32_t n, int32_t *sa);
+
+/* ---- database ---- */
+int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out);
+void prb_db_close(prb_db *db);
+int prb_db_info(const prb_db *db, int32_t *hash_size, int32_t *repeat_flag, int32_t *maximal_span,
+                int32_t *min_accessible_length, int32_t *npages);
+int prb_db_page_info(const prb_db *db, int32_t page, int32_t *nseq, int64_t *nchars);
+/* name / reference-style lengths of sequence `id` of `page` (db_reader.cpp:107-131) */
+const char *prb_db_seq_name(const prb_db *db, int32_t page, int32_t id);
+int prb_db_seq_lengths(const prb_db *db, int32_t page, int32_t id, int32_t *length,
+                       int32_t *length_unmasked, int32_t *start_pos);
+/* build a database from sequences (same files the reference's `db` step writes;
+ * db_construction.cpp:37-83): accessibilities on the GPU, SA + k-mer table on the host. */
+int prb_db_build(prb_ctx *ctx, const char *prefix, int32_t nseq, const char *const *names,
+                 const char *seqs, const int64_t *offsets, int32_t repeat_flag, int32_t hash_size,
+                 int32_t maximal_span, int32_t min_accessible_length, int32_t page_size);
+
+/* ---- query batches ---- */
+int prb_qbatch_create(prb_ctx *ctx, int32_t nq, const char *seqs, const int64_t *offsets,
+                      int32_t repeat_flag, prb_qbatch **out);
+void prb_qbatch_destroy(prb_qbatch *qb);
+/* runs Raccess for every query of the batch; results stay in HBM for the search stages */
+int prb_qbatch_accessibility(prb_ctx *ctx, prb_qbatch *qb, int32_t maximal_span,
+                             int32_t min_accessible_length);
+/* copies of the per-query arrays (NULL pointers are skipped) */
+int prb_qbatch_get(prb_qbatch *qb, int32_t q, uint8_t *enc, int32_t *sa, float *acc, float *cond);
+int32_t prb_qbatch_length_unmasked(const prb_qbatch *qb, int32_t q);
+
+/* ---- stages 3-5: seed search, ungapped and gapped extension for all queries of a batch
+ * against one page.  last_stage: 1 = seeds, 2 = after ungapped extension + filter,
+ * 3 = final (after gapped extension + filter). ---- */
+int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, const prb_ris_opts *opts,
+                    int32_t last_stage, prb_hitset **out);
+int64_t prb_hitset_size(const prb_hitset *hs);
+const prb_hit *prb_hitset_hits(const prb_hitset *hs);
+/* pairs (q, db) as int32[2], indexed by prb_hit.bp_offset */
+const int32_t *prb_hitset_basepairs(const prb_hitset *hs, int64_t *count);
+/* number of hits per stage for the whole call: seeds, after ungapped+filter, final */
+void prb_hitset_counts(const prb_hitset *hs, int64_t counts[3]);
+void prb_hitset_free(prb_hitset *hs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,196 @@
+"""ctypes binding of priblast_amd/lib/libpriblast_hip.so (include/priblast_hip.h).
+
+This is plumbing for tests and bench.py; the product is the shared library and the
+`pRIblast-hip` command line.  There is no CPU fallback: if the library is missing it raises,
+and on a machine without a GPU `Context()` raises with the library's error text.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(ROOT, "lib", "libpriblast_hip.so")
+BIN_PATH = os.path.join(ROOT, "bin", "pRIblast-hip")
+PARAMS = os.path.join(ROOT, "params", "rna_andronescu2007.par")
+
+c_i32, c_i64, c_dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+P = ctypes.POINTER
+
+
+class RisOpts(ctypes.Structure):
+    _fields_ = [("max_seed_length", c_i32), ("hybrid_threshold", c_dbl), ("interaction_threshold", c_dbl),
+                ("final_threshold", c_dbl), ("drop_out_wo_gap", c_i32), ("drop_out_w_gap", c_i32),
+                ("min_helix_length", c_i32), ("output_style", c_i32)]
+
+
+class Hit(ctypes.Structure):
+    _fields_ = [("q_sp", c_i32), ("db_sp", c_i32), ("q_len", c_i32), ("db_len", c_i32), ("db_id", c_i32),
+                ("db_id_start", c_i32), ("e_acc", c_dbl), ("e_hyb", c_dbl), ("e_tot", c_dbl), ("query", c_i32),
+                ("bp_count", c_i32), ("bp_offset", c_i64)]
+
+
+HIT_DTYPE = np.dtype([("q_sp", "<i4"), ("db_sp", "<i4"), ("q_len", "<i4"), ("db_len", "<i4"), ("db_id", "<i4"),
+                      ("db_id_start", "<i4"), ("e_acc", "<f8"), ("e_hyb", "<f8"), ("e_tot", "<f8"),
+                      ("query", "<i4"), ("bp_count", "<i4"), ("bp_offset", "<i8")])
+assert HIT_DTYPE.itemsize == ctypes.sizeof(Hit)
+
+# every symbol include/priblast_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "prb_last_error": (ctypes.c_char_p, []),
+    "prb_version": (ctypes.c_char_p, []),
+    "prb_ris_opts_default": (None, [P(RisOpts)]),
+    "prb_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, P(ctypes.c_void_p)]),
+    "prb_ctx_destroy": (None, [ctypes.c_void_p]),
+    "prb_ctx_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "prb_ctx_stage_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, P(c_dbl), P(c_i64)]),
+    "prb_ctx_reset_timers": (None, [ctypes.c_void_p]),
+    "prb_accessibility": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_char_p, ctypes.c_void_p, c_i32, c_i32,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "prb_accessibility_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_i32, c_i32, c_i32,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "prb_encode_query": (ctypes.c_int, [ctypes.c_char_p, c_i32, c_i32, ctypes.c_void_p]),
+    "prb_suffix_array": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p]),
+    "prb_db_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, P(ctypes.c_void_p)]),
+    "prb_db_close": (None, [ctypes.c_void_p]),
+    "prb_db_info": (ctypes.c_int, [ctypes.c_void_p, P(c_i32), P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
+    "prb_db_page_info": (ctypes.c_int, [ctypes.c_void_p, c_i32, P(c_i32), P(c_i64)]),
+    "prb_db_seq_name": (ctypes.c_char_p, [ctypes.c_void_p, c_i32, c_i32]),
+    "prb_db_seq_lengths": (ctypes.c_int, [ctypes.c_void_p, c_i32, c_i32, P(c_i32), P(c_i32), P(c_i32)]),
+    "prb_db_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_i32, P(ctypes.c_char_p), ctypes.c_char_p,
+                                    ctypes.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "prb_qbatch_create": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_char_p, ctypes.c_void_p, c_i32,
+                                         P(ctypes.c_void_p)]),
+    "prb_qbatch_destroy": (None, [ctypes.c_void_p]),
+    "prb_qbatch_accessibility": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i32, c_i32]),
+    "prb_qbatch_get": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p]),
+    "prb_qbatch_length_unmasked": (c_i32, [ctypes.c_void_p, c_i32]),
+    "prb_search_page": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i32, P(RisOpts), c_i32,
+                                       P(ctypes.c_void_p)]),
+    "prb_hitset_size": (c_i64, [ctypes.c_void_p]),
+    "prb_hitset_hits": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "prb_hitset_basepairs": (ctypes.c_void_p, [ctypes.c_void_p, P(c_i64)]),
+    "prb_hitset_counts": (None, [ctypes.c_void_p, P(c_i64)]),
+    "prb_hitset_free": (None, [ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def build():
+    """Compile the HIP library (and the ris driver) in-tree for gfx950."""
+    subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "csrc")], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            if not hasattr(L, name):  # reported by tests/test_host.py, not here
+                continue
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class PrbError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise PrbError(f"libpriblast_hip error {rc}: {lib().prb_last_error().decode()}")
+
+
+def _concat(seqs):
+    offs = np.zeros(len(seqs) + 1, np.int64)
+    for i, s in enumerate(seqs):
+        offs[i + 1] = offs[i] + len(s)
+    return "".join(seqs).encode(), offs
+
+
+def encode_query(seq, repeat_flag=0):
+    enc = np.zeros(len(seq) + 1, np.uint8)
+    _check(lib().prb_encode_query(seq.encode(), len(seq), repeat_flag, enc.ctypes.data))
+    return enc
+
+
+def suffix_array(text):
+    text = np.ascontiguousarray(text, np.uint8)
+    sa = np.zeros(len(text), np.int32)
+    _check(lib().prb_suffix_array(text.ctypes.data, len(text), sa.ctypes.data))
+    return sa
+
+
+def default_opts(**kw):
+    o = RisOpts()
+    lib().prb_ris_opts_default(ctypes.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    def __init__(self, device=0, param_file=None):
+        h = ctypes.c_void_p()
+        _check(lib().prb_ctx_create(device, param_file.encode() if param_file else PARAMS.encode(), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().prb_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def accessibility(self, seqs, W=70, delta=5):
+        """Raccess for a list of sequences -> list of (acc, cond) float32 arrays."""
+        buf, offs = _concat(seqs)
+        total = int(offs[-1])
+        acc = np.zeros(max(total, 1), np.float32)
+        cond = np.zeros(max(total, 1), np.float32)
+        _check(lib().prb_accessibility(self.h, len(seqs), buf, offs.ctypes.data, W, delta, acc.ctypes.data,
+                                       cond.ctypes.data))
+        return [(acc[offs[i]:offs[i + 1]], cond[offs[i]:offs[i + 1]]) for i in range(len(seqs))]
+
+    def accessibility_tables(self, seq, W=70, delta=5):
+        L = len(seq)
+        acc = np.zeros(max(L, 1), np.float32)
+        cond = np.zeros(max(L, 1), np.float32)
+        out = {"alpha_outer": np.zeros(L + 1), "beta_outer": np.zeros(L + 1)}
+        names = ["stem", "stemend", "multi", "multibif", "multi1", "multi2"]
+        ptrs = (ctypes.c_void_p * 12)()
+        k = 0
+        for side in ("alpha", "beta"):
+            for nm in names:
+                t = np.zeros((L + 1, W + 2))
+                out[f"{side}_{nm}"] = t
+                ptrs[k] = t.ctypes.data
+                k += 1
+        _check(lib().prb_accessibility_tables(self.h, seq.encode(), L, W, delta, acc.ctypes.data, cond.ctypes.data,
+                                              out["alpha_outer"].ctypes.data, out["beta_outer"].ctypes.data, ptrs))
+        return acc[:L], cond[:L], out
+
+    def stage_ms(self, stage):
+        ms, n = c_dbl(), c_i64()
+        _check(lib().prb_ctx_stage_ms(self.h, stage.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def reset_timers(self):
+        lib().prb_ctx_reset_timers(self.h)
+
+    def synchronize(self):
+        _check(lib().prb_ctx_synchronize(self.h))

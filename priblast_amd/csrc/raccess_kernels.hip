@@ -1,0 +1,714 @@
+// Raccess on gfx950: windowed McCaskill inside/outside and the accessibility of every
+// length-delta window (what Raccess::Run(seq, acc, cond) computes, raccess.cpp:42-50).
+//
+// Mapping (DESIGN.md "Raccess kernels"): one 64-lane wavefront owns one sequence and walks
+// the DP column by column (column = end position); the <= W-1 cells of a column sit on the
+// lanes (64 per pass).  A column is processed as phases that are parallel over cells, in
+// the dependency order derived in SURVEY.md 8(a'); every sum is folded in the reference's
+// order by the lane that owns the cell (bit-exact), and the (u1,u2) interior-loop
+// enumeration is wave-uniform so the loop-energy branch never diverges.  Band tables live in
+// HBM in END-MAJOR layout T[end][span], so the lanes of a column read and write contiguous
+// doubles; the exp/log tables and the small Turner tables are staged in LDS once per
+// workgroup (4 waves = 4 sequences share one image).
+//
+//   k_inside   <-> Raccess::CalcInsideVariable   raccess.cpp:99-242
+//   k_outside  <-> Raccess::CalcOutsideVariable  raccess.cpp:258-412
+//   k_biloop   <-> CalcBulgeAndInternalProbability / CalcLogSum...  raccess.cpp:614-771
+//   k_access   <-> CalcAccessibility + Exterior/Hairpin/Multi probabilities  raccess.cpp:484-612
+#include "raccess_kernels.hpp"
+
+#include "raccess_device.hpp"
+
+namespace prb {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+// band table ids inside one sequence's workspace block
+enum : int {
+  A_STEM = 0, A_STEMEND, A_MULTI, A_MULTIBIF, A_MULTI1, A_MULTI2, A_MULTI1_T,
+  B_STEM, B_STEMEND, B_MULTI, B_MULTIBIF, B_MULTI1, B_MULTI2
+};
+static_assert(B_MULTI2 + 1 == kRaBands, "band count");
+enum : int { V_AO = 0, V_BO, V_BP, V_CBP, V_BFLAG, V_CFLAG };
+
+struct SeqView {
+  int L, W, S;  // S = W + 2 = row length of a band
+  int64_t rows; // L + 2
+  double *band;
+  double *vec;
+  const unsigned char *s; // codes 0..4: s[0] = 0, s[1..L], s[L+1] = 0
+  int64_t out_off;
+  __device__ __forceinline__ double *tab(int t) const { return band + (int64_t)t * rows * S; }
+  __device__ __forceinline__ double *v(int t) const { return vec + (int64_t)t * rows; }
+};
+
+__device__ __forceinline__ SeqView make_view(const RaBatch &b, int idx) {
+  const RaSeqDesc d = b.desc[idx];
+  SeqView v;
+  v.L = d.L;
+  v.W = b.W;
+  v.S = b.W + 2;
+  v.rows = (int64_t)d.L + 2;
+  v.band = b.band + d.band_off;
+  v.vec = b.vec + d.vec_off;
+  v.s = b.codes + d.code_off;
+  v.out_off = d.out_off;
+  return v;
+}
+
+// element (start, end) of an end-major band: row `end`, column `end - start`
+#define EM(tab, start, end) ((tab)[(int64_t)(end) * S + ((end) - (start))])
+// start-major copy (alpha_multi1 only): row `start`, column `end - start`
+#define SM(tab, start, end) ((tab)[(int64_t)(start) * S + ((end) - (start))])
+
+// Orders this wave's global stores before its later loads issued by other lanes.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Raccess::CalcDangleEnergy, raccess.cpp:244-256
+__device__ __forceinline__ double dangle_energy(const RaLds &lds, const SeqView &v, int type, int a, int b) {
+  using SL = RaSmallLayout;
+  double x = 0;
+  if (type != 0) {
+    if (a > 0) x += lds.small[SL::kDangle5 + type * 5 + v.s[a]];
+    if (b < v.L) x += lds.small[SL::kDangle3 + type * 5 + v.s[b + 1]];
+    if (b == v.L && type > 2) x += lds.small[SL::kTermAU];
+  }
+  return x;
+}
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+__global__ void k_fill(double *p, int64_t n, double value) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = value;
+}
+
+// ------------------------------------------------------------------------------ inside
+__global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
+  __shared__ RaLds lds;
+  ra_load_lds(lds, c);
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (idx >= b.nseq) return;
+  using SL = RaSmallLayout;
+  const SeqView v = make_view(b, idx);
+  const int L = v.L, W = v.W, S = v.S;
+  const unsigned char *s = v.s;
+  double *a_stem = v.tab(A_STEM), *a_stemend = v.tab(A_STEMEND), *a_multi = v.tab(A_MULTI);
+  double *a_multibif = v.tab(A_MULTIBIF), *a_multi1 = v.tab(A_MULTI1), *a_multi2 = v.tab(A_MULTI2);
+  double *a_multi1t = v.tab(A_MULTI1_T);
+  double *ao = v.v(V_AO);
+  const double MLbase = lds.small[SL::kMLbase], MLintern = lds.small[SL::kMLintern],
+               MLclosing = lds.small[SL::kMLclosing];
+
+  for (int j = kTurn + 1; j <= L; j++) {
+    // cells of column j: spans d = 3..dmax, start i = j - d >= max(0, j-W-1).
+    // lane mapping: d = dtop - lane, dtop = dmax, dmax-64, ...  (the last pass holds the
+    // small spans, which are the cheap ones in every inside phase)
+    const int dmax = imin(j, W + 1);
+
+    // phase 1: Alpha_stem (raccess.cpp:102-129) and Alpha_multi2 (:145-162): both need only
+    // column j-1 and the cell itself.
+    for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+      const int d = dtop - lane;
+      if (d < kTurn) continue;
+      const int i = j - d;
+      const int type = ra_bp(lds, s[i + 1], s[j]);
+      double stem = kNegInf;
+      if (type != 0) {
+        const int type2 = ra_rtype(ra_bp(lds, s[i + 2], s[j - 1]));
+        double temp = 0;
+        bool flag = false;
+        const double ps = EM(a_stem, i + 1, j - 1), pe = EM(a_stemend, i + 1, j - 1);
+        if (ps != kNegInf) {
+          if (type2 != 0) temp = ps + lds.small[SL::kStack + type * 7 + type2];
+          flag = true;
+        }
+        if (pe != kNegInf) {
+          temp = flag ? ra_lse(lds, temp, pe) : pe;
+          flag = true;
+        }
+        stem = flag ? temp : kNegInf;
+      }
+      EM(a_stem, i, j) = stem;
+      double temp = 0;
+      bool flag = false;
+      if (type != 0 && stem != kNegInf) {
+        temp = stem + MLintern + dangle_energy(lds, v, type, i, j);
+        flag = true;
+      }
+      const double prev = EM(a_multi2, i, j - 1);
+      double m2;
+      if (prev != kNegInf) {
+        m2 = prev + MLbase;
+        if (flag) m2 = ra_lse(lds, temp, m2);
+      } else {
+        m2 = flag ? temp : kNegInf;
+      }
+      EM(a_multi2, i, j) = m2;
+    }
+    wave_sync();
+
+    // phase 2: Alpha_multibif (:131-143) then Alpha_multi1 (:164-175)
+    for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+      const int d = dtop - lane;
+      if (d < kTurn) continue;
+      const int i = j - d;
+      double temp = 0;
+      bool flag = false;
+      for (int t = 1; t < d; t++) { // k = i + t
+        const double m1 = EM(a_multi1, i, i + t), m2 = EM(a_multi2, i + t, j);
+        if (m1 != kNegInf && m2 != kNegInf) {
+          temp = flag ? ra_lse(lds, temp, m1 + m2) : m1 + m2;
+          flag = true;
+        }
+      }
+      const double mb = flag ? temp : kNegInf;
+      EM(a_multibif, i, j) = mb;
+      const double m2 = EM(a_multi2, i, j);
+      double m1;
+      if (m2 != kNegInf && mb != kNegInf) m1 = ra_lse(lds, m2, mb);
+      else if (m2 == kNegInf) m1 = mb;
+      else m1 = m2;
+      EM(a_multi1, i, j) = m1;
+      SM(a_multi1t, i, j) = m1;
+    }
+    wave_sync();
+
+    // phase 3, two serial chains on two lanes: Alpha_multi (:177-191), i descending, and
+    // Alpha_outer[j] (:230-241), p ascending.
+    if (lane == 0) {
+      double prev = kNegInf; // Alpha_multi[i+1][..] of the first cell (d = 3) is never written
+      for (int d = kTurn; d <= dmax; d++) {
+        const int i = j - d;
+        const double mb = EM(a_multibif, i, j);
+        double m;
+        if (prev != kNegInf) {
+          m = prev + MLbase;
+          if (mb != kNegInf) m = ra_lse(lds, m, mb);
+        } else {
+          m = mb;
+        }
+        EM(a_multi, i, j) = m;
+        prev = m;
+      }
+    } else if (lane == 1) {
+      double temp = ao[j - 1];
+      for (int p = j - dmax; p < j; p++) {
+        const double st = EM(a_stem, p, j);
+        if (st != kNegInf) {
+          const int type = ra_bp(lds, s[p + 1], s[j]);
+          const double x = st + dangle_energy(lds, v, type, p, j);
+          temp = ra_lse(lds, temp, x + ao[p]);
+        }
+      }
+      ao[j] = temp;
+    }
+    wave_sync();
+
+    // phase 4: Alpha_stemend (:193-226).  Interior loops (u1 = p - i, u2 = j - q) are
+    // enumerated wave-uniformly in the reference's order: p ascending, q ascending.
+    if (j != L) {
+      const int bj = s[j]; // = s[j'-1] for the closing pair (i, j' = j+1)
+      for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+        const int d = dtop - lane;
+        const bool cell = d >= kTurn;
+        const int i = cell ? j - d : 0;
+        const int type = cell ? ra_bp(lds, s[i], s[j + 1]) : 0;
+        const int bi1 = cell ? s[i + 1] : 0;
+        double temp = type != 0 ? ra_hairpin_energy(lds, type, d, bi1, bj) : 0.0;
+        // p <= j-5 and q >= p+5  <=>  u1 + u2 <= d - 5; the pass bound uses dtop
+        const int m = imin(kMaxLoop, dtop - (kTurn + 2));
+        for (int u1 = 0; u1 <= m; u1++) {
+          for (int u2 = imin(kMaxLoop - u1, dtop - (kTurn + 2) - u1); u2 >= 0; u2--) {
+            if (u1 == 0 && u2 == 0) continue; // the (p,q) == (i,j) term is excluded (:207)
+            const int q = j - u2;
+            if (type != 0 && u1 + u2 <= d - (kTurn + 2)) {
+              const int p = i + u1;
+              const double st = EM(a_stem, p, q);
+              if (st != kNegInf) {
+                int type2 = ra_bp(lds, s[p + 1], s[q]);
+                if (type2 != 0) {
+                  type2 = ra_rtype(type2);
+                  const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2, bi1, bj, s[p], s[q + 1]);
+                  temp = ra_lse(lds, temp, st + z);
+                }
+              }
+            }
+          }
+        }
+        if (cell) {
+          double out = kNegInf;
+          if (type != 0) {
+            const int tt = ra_rtype(type);
+            out = ra_lse(lds, temp,
+                         EM(a_multi, i, j) + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + bi1] +
+                             lds.small[SL::kDangle5 + tt * 5 + bj]);
+          }
+          EM(a_stemend, i, j) = out;
+        }
+      }
+    }
+    wave_sync();
+  }
+}
+
+// ----------------------------------------------------------------------------- outside
+__global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
+  __shared__ RaLds lds;
+  ra_load_lds(lds, c);
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (idx >= b.nseq) return;
+  using SL = RaSmallLayout;
+  const SeqView v = make_view(b, idx);
+  const int L = v.L, W = v.W, S = v.S;
+  const unsigned char *s = v.s;
+  const double *a_stem = v.tab(A_STEM), *a_multi2 = v.tab(A_MULTI2), *a_multi1t = v.tab(A_MULTI1_T);
+  double *b_stem = v.tab(B_STEM), *b_stemend = v.tab(B_STEMEND), *b_multi = v.tab(B_MULTI);
+  double *b_multibif = v.tab(B_MULTIBIF), *b_multi1 = v.tab(B_MULTI1), *b_multi2 = v.tab(B_MULTI2);
+  const double *ao = v.v(V_AO);
+  double *bo = v.v(V_BO);
+  const double MLbase = lds.small[SL::kMLbase], MLintern = lds.small[SL::kMLintern],
+               MLclosing = lds.small[SL::kMLclosing];
+
+  // Beta_outer[i] (raccess.cpp:260-271) is a serial chain over i descending that only reads
+  // Alpha_stem; it runs on lane 1 one position ahead of the column loop.
+  auto beta_outer_at = [&](int i) {
+    double temp = bo[i + 1];
+    for (int p = i + 1; p <= imin(i + W + 1, L); p++) {
+      const double st = EM(a_stem, i, p);
+      if (st != kNegInf) {
+        const int type = ra_bp(lds, s[i + 1], s[p]);
+        const double x = st + dangle_energy(lds, v, type, i, p);
+        temp = ra_lse(lds, temp, x + bo[p]);
+      }
+    }
+    bo[i] = temp;
+  };
+
+  for (int q = L; q >= kTurn + 1; q--) {
+    // cells of column q: p = max(0,q-W-1) .. q-3 ascending <=> d = q - p descending from dmax.
+    // lane mapping: d = dbot + lane, dbot = 3, 67, ... (the last pass holds the large
+    // spans, which are the cheap ones in every outside phase)
+    const int dmax = imin(q, W + 1);
+
+    // phase A: Beta_stemend (:278-279), copy from column q+1
+    if (q != L) {
+      for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
+        const int d = dbot + lane;
+        if (d > dmax) continue;
+        const int p = q - d;
+        if (p != 0) EM(b_stemend, p, q) = d >= W ? kNegInf : EM(b_stem, p - 1, q + 1);
+      }
+    }
+    wave_sync();
+
+    // phase B, serial chains: Beta_multi (:281-308), p ascending, on lane 0;
+    // Beta_outer[q-1] on lane 1.
+    if (lane == 0) {
+      if (q != L) {
+        for (int d = dmax; d >= kTurn; d--) {
+          const int p = q - d;
+          if (p == 0) continue;
+          double temp = 0;
+          bool flag = false;
+          if (d + 1 <= W + 1) {
+            const double pm = EM(b_multi, p - 1, q);
+            if (pm != kNegInf) {
+              temp = pm + MLbase;
+              flag = true;
+            }
+          }
+          const int tt = ra_rtype(ra_bp(lds, s[p], s[q + 1]));
+          const double se = EM(b_stemend, p, q);
+          if (se != kNegInf) {
+            const double x = se + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + s[p + 1]] +
+                             lds.small[SL::kDangle5 + tt * 5 + s[q]];
+            temp = flag ? ra_lse(lds, temp, x) : x;
+          } else if (!flag) {
+            temp = kNegInf;
+          }
+          EM(b_multi, p, q) = temp;
+        }
+      }
+    } else if (lane == 1) {
+      beta_outer_at(q - 1);
+    }
+    wave_sync();
+
+    if (q != L) {
+      // phase C: Beta_multi1 (:310-324) then Beta_multibif (:354-364)
+      for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
+        const int d = dbot + lane;
+        if (d > dmax) continue;
+        const int p = q - d;
+        if (p == 0) continue;
+        double temp = 0;
+        bool flag = false;
+        const int kend = imin(L, p + W);
+        for (int k = q + 1; k <= kend; k++) {
+          const double bb = EM(b_multibif, p, k), m2 = EM(a_multi2, q, k);
+          if (bb != kNegInf && m2 != kNegInf) {
+            temp = flag ? ra_lse(lds, temp, bb + m2) : bb + m2;
+            flag = true;
+          }
+        }
+        const double m1 = flag ? temp : kNegInf;
+        EM(b_multi1, p, q) = m1;
+        const double mm = EM(b_multi, p, q);
+        double mb;
+        if (m1 != kNegInf && mm != kNegInf) mb = ra_lse(lds, m1, mm);
+        else if (mm == kNegInf) mb = m1;
+        else mb = mm;
+        EM(b_multibif, p, q) = mb;
+      }
+      wave_sync();
+
+      // phase D: Beta_multi2 (:326-352)
+      for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
+        const int d = dbot + lane;
+        if (d > dmax) continue;
+        const int p = q - d;
+        if (p == 0) continue;
+        double temp = 0;
+        bool flag = false;
+        const double m1 = EM(b_multi1, p, q);
+        if (m1 != kNegInf) {
+          temp = m1;
+          flag = true;
+        }
+        if (d <= W) {
+          const double nx = EM(b_multi2, p, q + 1);
+          if (nx != kNegInf) {
+            temp = flag ? ra_lse(lds, temp, nx + MLbase) : nx + MLbase;
+            flag = true;
+          }
+        }
+        for (int k = imax(0, q - W); k < p; k++) {
+          const double bb = EM(b_multibif, k, q), a1 = SM(a_multi1t, k, p);
+          if (bb != kNegInf && a1 != kNegInf) {
+            temp = flag ? ra_lse(lds, temp, bb + a1) : bb + a1;
+            flag = true;
+          }
+        }
+        EM(b_multi2, p, q) = flag ? temp : kNegInf;
+      }
+      wave_sync();
+    }
+
+    // phase E: Beta_stem (:367-409).  Enclosing pairs (i = p - u1, j+1 = q + u2 + 1) are
+    // enumerated wave-uniformly in the reference's order: i ascending, j ascending.
+    for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
+      const int d = dbot + lane;
+      const bool cell = d <= dmax;
+      const int p = cell ? q - d : 1;
+      const int t2raw = cell ? ra_bp(lds, s[p + 1], s[q]) : 0;
+      const int type2 = ra_rtype(t2raw);
+      const int bp0 = cell ? s[p] : 0, bq1 = cell ? s[q + 1] : 0;
+      double temp = 0;
+      if (t2raw != 0) temp = ao[p] + bo[q] + dangle_energy(lds, v, t2raw, p, q);
+      // j - i = d + u1 + u2 <= W + 1; the pass bound uses dbot
+      const int m = imin(kMaxLoop, W + 1 - dbot);
+      const int u1top = imin(m, q - dbot - 1); // i >= 1 for the smallest span of the pass
+      for (int u1 = u1top; u1 >= 0; u1--) {
+        const int u2top = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - dbot - u1);
+        for (int u2 = 0; u2 <= u2top; u2++) {
+          if (u1 == 0 && u2 == 0) continue; // (i,j) == (p,q) is excluded (:377)
+          const int j = q + u2;
+          if (t2raw != 0 && u1 <= p - 1 && d + u1 + u2 <= W + 1) {
+            const int i = p - u1;
+            const int type = ra_bp(lds, s[i], s[j + 1]);
+            if (type != 0) {
+              const double se = EM(b_stemend, i, j);
+              if (se != kNegInf) {
+                const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2, s[i + 1], s[j], bp0, bq1);
+                temp = ra_lse(lds, temp, se + z);
+              }
+            }
+          }
+        }
+      }
+      if (cell) {
+        double out = kNegInf;
+        if (t2raw != 0) {
+          if (p != 0 && q != L) {
+            const int type = ra_bp(lds, bp0, bq1);
+            if (type != 0 && d + 2 <= W + 1) {
+              const double ps = EM(b_stem, p - 1, q + 1);
+              if (ps != kNegInf) temp = ra_lse(lds, temp, ps + lds.small[SL::kStack + type * 7 + type2]);
+            }
+          }
+          out = temp;
+          const double m2 = EM(b_multi2, p, q);
+          if (m2 != kNegInf) {
+            const double x = m2 + MLintern + dangle_energy(lds, v, t2raw, p, q);
+            out = ra_lse(lds, x, out);
+          }
+        }
+        EM(b_stem, p, q) = out;
+      }
+    }
+    wave_sync();
+  }
+  // remaining Beta_outer positions (columns stop at q = 4)
+  if (lane == 1)
+    for (int i = (L >= kTurn + 1 ? kTurn - 1 : L - 1); i >= 0; i--) beta_outer_at(i);
+}
+
+// ------------------------------------------------------------- bulge / interior loops
+// Ordered scatter of every interior-loop term into the positions it makes accessible
+// (raccess.cpp:626-665 / :695-752).  The sums per position k are sequential in the
+// reference, so tuples are applied one at a time in (i, j, p, q) order; the lanes own the
+// positions (k mod 64, two slots for windows up to 128), so one tuple updates all its
+// positions in one predicated instruction.
+template <bool kLogSum>
+__device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v, int delta, int lane) {
+  const int L = v.L, W = v.W, S = v.S;
+  const unsigned char *s = v.s;
+  const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
+  double *bp = v.v(V_BP), *cbp = v.v(V_CBP), *bfl = v.v(V_BFLAG), *cfl = v.v(V_CFLAG);
+  // accumulators of position k live on lane k & 63, slot (k >> 6) & 1
+  double accb0 = 0, accb1 = 0, accc0 = 0, accc1 = 0;
+  bool fb0 = false, fb1 = false, fc0 = false, fc1 = false;
+
+  for (int i = 1; i < L - kTurn - 2; i++) {
+    const int kb = i + 1; // smallest position this and later i can touch
+    const int jend = imin(i + W, L);
+    for (int j = i + kTurn + 3; j <= jend; j++) {
+      const int type = ra_bp(lds, s[i], s[j]);
+      if (type == 0) continue;
+      const double bs = EM(b_stemend, i, j - 1);
+      if (bs == kNegInf) continue;
+      const int D = j - i;
+      const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
+      const int bi1 = s[i + 1], bj1 = s[j - 1];
+      for (int u1 = 0; u1 <= m; u1++) {
+        // lanes take the q of this p in the reference's order: q ascending <=> u2 descending
+        const int p = i + 1 + u1;
+        const int u2 = (m - u1) - lane;
+        bool valid = u2 >= 0 && !(u1 == 0 && u2 == 0);
+        double val = 0;
+        int q = 0;
+        if (valid) {
+          q = j - 1 - u2;
+          int type2 = ra_bp(lds, s[p], s[q]);
+          const double as = EM(a_stem, p - 1, q);
+          valid = type2 != 0 && as != kNegInf;
+          if (valid) {
+            type2 = ra_rtype(type2);
+            const double e = bs + ra_loop_energy(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
+            val = kLogSum ? e : ra_expd(lds, e);
+          }
+        }
+        unsigned long long mask = __ballot(valid);
+        const int kl1 = p - delta; // left range [i+1, p-delta]
+        while (mask) {
+          const int src = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const double tv = __shfl(val, src);
+          const int tq = __shfl(q, src);
+          const int kr0 = tq + 1, kr1 = j - delta; // right range [q+1, j-delta]
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int k = kb + ((lane - kb) & 63) + 64 * h;
+            const bool inl = k <= kl1; // k >= kb = i+1 always
+            const bool inr = k >= kr0 && k <= kr1;
+            if (inl || inr) {
+              const bool last = inl ? k == kl1 : k == kr1;
+              const bool sl = (k >> 6) & 1;
+              if (!kLogSum) {
+                if (last) { if (sl) accb1 += tv; else accb0 += tv; }
+                else { if (sl) accc1 += tv; else accc0 += tv; }
+              } else {
+                if (last) {
+                  const double cur = sl ? accb1 : accb0;
+                  const bool f = sl ? fb1 : fb0;
+                  const double nv = f ? ra_lse(lds, cur, tv) : tv;
+                  if (sl) { accb1 = nv; fb1 = true; } else { accb0 = nv; fb0 = true; }
+                } else {
+                  const double cur = sl ? accc1 : accc0;
+                  const bool f = sl ? fc1 : fc0;
+                  const double nv = f ? ra_lse(lds, cur, tv) : tv;
+                  if (sl) { accc1 = nv; fc1 = true; } else { accc0 = nv; fc0 = true; }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // position k = i+1 receives nothing from later i: store it and recycle the slot
+    if ((kb & 63) == lane) {
+      const bool sl = (kb >> 6) & 1;
+      bp[kb - 1] = sl ? accb1 : accb0;
+      cbp[kb - 1] = sl ? accc1 : accc0;
+      bfl[kb - 1] = (sl ? fb1 : fb0) ? 1.0 : 0.0;
+      cfl[kb - 1] = (sl ? fc1 : fc0) ? 1.0 : 0.0;
+      if (sl) { accb1 = 0; accc1 = 0; fb1 = false; fc1 = false; }
+      else { accb0 = 0; accc0 = 0; fb0 = false; fc0 = false; }
+    }
+  }
+  // positions beyond the last i keep their zero-initialised value: every position that
+  // can receive a term (k <= L - delta, k >= 2) has been flushed when i passed k - 1,
+  // except those with k - 1 >= L - 5; flush what the last windows left behind.
+  for (int k = imax(2, L - kTurn - 2 + 1); k <= L; k++) {
+    if ((k & 63) == lane) {
+      const bool sl = (k >> 6) & 1;
+      bp[k - 1] = sl ? accb1 : accb0;
+      cbp[k - 1] = sl ? accc1 : accc0;
+      bfl[k - 1] = (sl ? fb1 : fb0) ? 1.0 : 0.0;
+      cfl[k - 1] = (sl ? fc1 : fc0) ? 1.0 : 0.0;
+      if (sl) { accb1 = 0; accc1 = 0; fb1 = false; fc1 = false; }
+      else { accb0 = 0; accc0 = 0; fb0 = false; fc0 = false; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
+  __shared__ RaLds lds;
+  ra_load_lds(lds, c);
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (idx >= b.nseq) return;
+  const SeqView v = make_view(b, idx);
+  const double pf = v.v(V_AO)[v.L];
+  if (pf >= -690 && pf <= 690) biloop_run<false>(lds, c, v, b.delta, lane); // raccess.cpp:500-507
+  else biloop_run<true>(lds, c, v, b.delta, lane);
+}
+
+// ---------------------------------------------------------------------- accessibility
+// One lane per window start x (raccess.cpp:510-527); hairpin (:536-579), multi (:581-612)
+// and exterior (:530-534) probabilities are gathers that are independent per x.
+__device__ __forceinline__ double multi_prob(const RaLds &lds, const SeqView &v, int x, int w) {
+  const int L = v.L, W = v.W, S = v.S;
+  const double *a_multi = v.tab(A_MULTI), *a_multi2 = v.tab(A_MULTI2);
+  const double *b_multi = v.tab(B_MULTI), *b_multi2 = v.tab(B_MULTI2);
+  double temp = 0;
+  bool flag = false;
+  for (int i = x + w - 1; i <= imin(x + W, L); i++) {
+    const double bb = EM(b_multi, x - 1, i), aa = EM(a_multi, x + w - 1, i);
+    if (bb != kNegInf && aa != kNegInf) {
+      temp = flag ? ra_lse(lds, temp, bb + aa) : bb + aa;
+      flag = true;
+    }
+  }
+  for (int i = imax(0, x + w - 1 - W); i < x; i++) {
+    const double bb = EM(b_multi2, i, x + w - 1), aa = EM(a_multi2, i, x - 1);
+    if (bb != kNegInf && aa != kNegInf) {
+      temp = flag ? ra_lse(lds, temp, bb + aa) : bb + aa;
+      flag = true;
+    }
+  }
+  return flag ? ra_expd(lds, temp - v.v(V_AO)[L]) : 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_access(RaBatch b, RaConst c) {
+  __shared__ RaLds lds;
+  ra_load_lds(lds, c);
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (idx >= b.nseq) return;
+  using SL = RaSmallLayout;
+  const SeqView v = make_view(b, idx);
+  const int L = v.L, W = v.W, S = v.S, delta = b.delta;
+  const unsigned char *s = v.s;
+  const double *b_stemend = v.tab(B_STEMEND);
+  const double *ao = v.v(V_AO), *bo = v.v(V_BO);
+  const double *bpv = v.v(V_BP), *cbpv = v.v(V_CBP), *bfl = v.v(V_BFLAG), *cfl = v.v(V_CFLAG);
+  const double Z = ao[L];
+  const double kT = lds.small[SL::kKT];
+  const bool logsum = !(Z >= -690 && Z <= 690);
+  float *acc = b.acc + v.out_off, *cond = b.cond + v.out_off;
+
+  for (int x = 1 + lane; x <= L; x += kWave) {
+    float acc_x = 0.0f;
+    const bool has_acc = x + delta - 1 <= L;
+    if (has_acc) {
+      // hairpin loops enclosing [x, x+delta-1] (:536-579)
+      double temp = 0, c_temp = 0;
+      bool flag = false, c_flag = false;
+      for (int i = imax(1, x - W); i < x; i++) {
+        for (int j = x + delta; j <= imin(i + W, L); j++) {
+          const double se = EM(b_stemend, i, j - 1);
+          if (se != kNegInf) {
+            const int type = ra_bp(lds, s[i], s[j]);
+            const double h = se + ra_hairpin_energy(lds, type, j - i - 1, s[i + 1], s[j - 1]);
+            if (j == x + delta) {
+              temp = flag ? ra_lse(lds, temp, h) : h;
+              flag = true;
+            } else {
+              c_temp = c_flag ? ra_lse(lds, c_temp, h) : h;
+              c_flag = true;
+            }
+          }
+        }
+      }
+      if (flag && c_flag) temp = ra_lse(lds, temp, c_temp);
+      if (!flag && c_flag) {
+        temp = c_temp;
+        flag = true;
+      }
+      const double hp = flag ? ra_expd(lds, temp - Z) : 0.0;
+      const double chp = c_flag ? ra_expd(lds, c_temp - Z) : 0.0;
+
+      // bulge / interior loop terms: finalisation of the scatter sums (:667-680 / :754-770)
+      double bl = bpv[x - 1], cbl = cbpv[x - 1];
+      if (!logsum) {
+        if (bl != 0) bl = ra_expd(lds, (double)ra_logf(lds, (float)(bl + cbl)) - Z);
+        if (cbl != 0) cbl = ra_expd(lds, (double)ra_logf(lds, (float)cbl) - Z);
+      } else {
+        const bool f1 = bfl[x - 1] != 0, f2 = cfl[x - 1] != 0;
+        if (f1 && f2) bl = ra_lse(lds, bl, cbl);
+        if (!f1 && f2) bl = cbl;
+        if (f1) bl = ra_expd(lds, bl - Z);
+        if (f2) cbl = ra_expd(lds, cbl - Z);
+      }
+
+      double prob = 0.0;
+      prob += ra_expd(lds, ao[x - 1] + bo[x + delta - 1] - Z);
+      prob += hp;
+      prob += bl;
+      prob += multi_prob(lds, v, x, delta);
+      acc_x = (float)(((double)(-ra_logf(lds, (float)prob)) * kT) / 1000);
+      acc[x - 1] = acc_x;
+
+      if (x + delta - 1 < L) {
+        double cp = 0.0;
+        cp += ra_expd(lds, ao[x - 1] + bo[x + delta] - Z);
+        cp += chp;
+        cp += cbl;
+        cp += multi_prob(lds, v, x, delta + 1);
+        cond[x + delta - 1] = (float)(((double)(-ra_logf(lds, (float)cp)) * kT) / 1000 - (double)acc_x);
+      }
+    }
+  }
+}
+
+} // namespace
+
+hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int64_t vec_elems,
+                     hipStream_t stream) {
+  if (b.nseq <= 0) return hipSuccess;
+  const int fill_blocks = 2048;
+  hipLaunchKernelGGL(k_fill, dim3(fill_blocks), dim3(256), 0, stream, b.band, band_elems, kNegInf);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, stream, b.vec, vec_elems, 0.0);
+  const int blocks = (b.nseq + kWavesPerBlock - 1) / kWavesPerBlock;
+  hipLaunchKernelGGL(k_inside, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  hipLaunchKernelGGL(k_outside, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  hipLaunchKernelGGL(k_biloop, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  hipLaunchKernelGGL(k_access, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  return hipGetLastError();
+}
+
+} // namespace prb

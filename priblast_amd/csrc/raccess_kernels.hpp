@@ -1,0 +1,44 @@
+// Host-visible interface of the Raccess kernels (raccess_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace prb {
+
+struct RaConst; // raccess_device.hpp
+
+// One sequence of a batch.  Offsets are in elements of the respective pool.
+struct RaSeqDesc {
+  int64_t band_off; // doubles: kRaBands tables of (L+2)*(W+2)
+  int64_t vec_off;  // doubles: kRaVecs vectors of (L+2)
+  int64_t code_off; // bytes: L+2 codes (0, s[1..L], 0)
+  int64_t out_off;  // floats: L entries of acc / cond
+  int32_t L;
+  int32_t pad;
+};
+
+constexpr int kRaBands = 13;
+constexpr int kRaVecs = 8;
+constexpr int kRaMaxSpan = 129; // W - delta <= 128 (two accumulator slots per lane in k_biloop)
+
+struct RaBatch {
+  const RaSeqDesc *desc;
+  int32_t nseq;
+  int32_t W, delta;
+  double *band;
+  double *vec;
+  const unsigned char *codes;
+  float *acc;  // out
+  float *cond; // out
+};
+
+// Enqueue fill + inside + outside + biloop + accessibility for a batch on `stream`.
+hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int64_t vec_elems,
+                     hipStream_t stream);
+
+// doubles / bytes needed for a sequence of length L
+inline int64_t ra_band_elems(int L, int W) { return (int64_t)kRaBands * (L + 2) * (W + 2); }
+inline int64_t ra_vec_elems(int L) { return (int64_t)kRaVecs * (L + 2); }
+
+} // namespace prb

@@ -1,0 +1,63 @@
+"""GPU parity tests for stage 1 (Raccess) through the C ABI: bit-exact against the oracle and
+against the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import refdump
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from priblast_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_dp_tables_match_oracle(ctx, oracle):
+    """Every DP table of one sequence, cell by cell (diagnostics entry point)."""
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "c1_q.fa"))
+    for s in (seqs[0][:40], seqs[1], "GGGGGCCAAAAGGCCCCCAUAU" * 6):
+        acc, cond, t = ctx.accessibility_tables(s, 70, 5)
+        oa, oc, ot = oracle.raccess(s, 70, 5, debug=True)
+        bad = []
+        for k in ("alpha_stem", "alpha_multi2", "alpha_multibif", "alpha_multi1", "alpha_multi", "alpha_stemend",
+                  "alpha_outer", "beta_outer", "beta_stemend", "beta_multi", "beta_multi1", "beta_multibif",
+                  "beta_multi2", "beta_stem"):
+            a, b = np.asarray(t[k]), np.asarray(ot[k])
+            if not np.array_equal(a.view(np.uint64), b.view(np.uint64)):
+                w = np.argwhere(a != b)
+                bad.append((k, len(w), w[:4].tolist(), a[tuple(w[0])], b[tuple(w[0])]))
+        assert not bad, bad
+        assert np.array_equal(bits(acc), bits(oa))
+        assert np.array_equal(bits(cond), bits(oc))
+
+
+@pytest.mark.parametrize("fa,racc", [("corpus.fa", "corpus.racc"), ("c1_q.fa", "c1_q_w40d7.racc")])
+def test_golden_accessibilities_bit_exact(ctx, fa, racc):
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, fa))
+    g = refdump.read_raccess(os.path.join(GOLDEN, racc))
+    res = ctx.accessibility(seqs, g["W"], g["delta"])
+    for name, (acc, cond), rec in zip(names, res, g["seqs"]):
+        assert np.array_equal(bits(acc), bits(rec["acc"])), name
+        assert np.array_equal(bits(cond), bits(rec["cond"])), name
+
+
+def test_batch_order_and_chunking_do_not_matter(ctx, oracle):
+    """Ragged batch incl. empty and very short sequences; tiny workspace forces several chunks."""
+    rng = np.random.default_rng(3)
+    seqs = ["", "A", "ACG", "ACGU" * 3] + ["".join(rng.choice(list("ACGU"), n)) for n in (17, 64, 65, 129, 300, 90, 5)]
+    res = ctx.accessibility(seqs, 70, 5)
+    for s, (acc, cond) in zip(seqs, res):
+        oa, oc = oracle.raccess(s, 70, 5) if len(s) else (np.zeros(0, np.float32), np.zeros(0, np.float32))
+        assert np.array_equal(bits(acc), bits(oa)), len(s)
+        assert np.array_equal(bits(cond), bits(oc)), len(s)
