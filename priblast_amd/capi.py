@@ -194,3 +194,92 @@ class Context:
 
     def synchronize(self):
         _check(lib().prb_ctx_synchronize(self.h))
+
+
+class Db:
+    """Database pages resident in HBM (prb_db_open)."""
+
+    def __init__(self, ctx, prefix):
+        h = ctypes.c_void_p()
+        _check(lib().prb_db_open(ctx.h, prefix.encode(), ctypes.byref(h)))
+        self.h, self.ctx = h, ctx
+        v = [c_i32() for _ in range(5)]
+        _check(lib().prb_db_info(self.h, *[ctypes.byref(x) for x in v]))
+        self.hash_size, self.repeat_flag, self.W, self.delta, self.npages = (x.value for x in v)
+
+    def close(self):
+        if self.h:
+            lib().prb_db_close(self.h)
+            self.h = None
+
+    def page_info(self, page):
+        n, c = c_i32(), c_i64()
+        _check(lib().prb_db_page_info(self.h, page, ctypes.byref(n), ctypes.byref(c)))
+        return n.value, c.value
+
+    def seq_name(self, page, i):
+        return lib().prb_db_seq_name(self.h, page, i).decode()
+
+    def seq_lengths(self, page, i):
+        a, b, c = c_i32(), c_i32(), c_i32()
+        _check(lib().prb_db_seq_lengths(self.h, page, i, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+
+def db_build(ctx, prefix, names, seqs, repeat_flag=0, hash_size=8, W=70, delta=5, page_size=2 ** 31 - 1):
+    buf, offs = _concat(seqs)
+    arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    _check(lib().prb_db_build(ctx.h, prefix.encode(), len(seqs), arr, buf, offs.ctypes.data, repeat_flag, hash_size, W,
+                              delta, page_size))
+
+
+class QBatch:
+    """A batch of queries: encoded + suffix arrays (host), accessibilities (GPU)."""
+
+    def __init__(self, ctx, seqs, repeat_flag=0):
+        buf, offs = _concat(seqs)
+        h = ctypes.c_void_p()
+        _check(lib().prb_qbatch_create(ctx.h, len(seqs), buf, offs.ctypes.data, repeat_flag, ctypes.byref(h)))
+        self.h, self.ctx, self.lens = h, ctx, [len(s) for s in seqs]
+
+    def close(self):
+        if self.h:
+            lib().prb_qbatch_destroy(self.h)
+            self.h = None
+
+    def accessibility(self, W, delta):
+        _check(lib().prb_qbatch_accessibility(self.ctx.h, self.h, W, delta))
+
+    def get(self, q):
+        L = self.lens[q]
+        enc = np.zeros(L + 1, np.uint8)
+        sa = np.zeros(L + 1, np.int32)
+        acc = np.zeros(max(L, 1), np.float32)
+        cond = np.zeros(max(L, 1), np.float32)
+        _check(lib().prb_qbatch_get(self.h, q, enc.ctypes.data, sa.ctypes.data, acc.ctypes.data, cond.ctypes.data))
+        return enc, sa, acc[:L], cond[:L]
+
+    def length_unmasked(self, q):
+        return lib().prb_qbatch_length_unmasked(self.h, q)
+
+
+def search_page(ctx, qb, db, page, opts=None, last_stage=3):
+    """-> (hits: structured array HIT_DTYPE, bp: int32 [n,2], counts (seed, ungapped, final))."""
+    o = opts or default_opts()
+    h = ctypes.c_void_p()
+    _check(lib().prb_search_page(ctx.h, qb.h, db.h, page, ctypes.byref(o), last_stage, ctypes.byref(h)))
+    try:
+        n = lib().prb_hitset_size(h)
+        hits = np.zeros(n, HIT_DTYPE)
+        if n:
+            ctypes.memmove(hits.ctypes.data, lib().prb_hitset_hits(h), n * HIT_DTYPE.itemsize)
+        cnt = c_i64()
+        p = lib().prb_hitset_basepairs(h, ctypes.byref(cnt))
+        bp = np.zeros((cnt.value, 2), np.int32)
+        if cnt.value:
+            ctypes.memmove(bp.ctypes.data, p, cnt.value * 8)
+        counts = (c_i64 * 3)()
+        lib().prb_hitset_counts(h, counts)
+        return hits, bp, tuple(counts)
+    finally:
+        lib().prb_hitset_free(h)

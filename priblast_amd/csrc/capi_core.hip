@@ -202,11 +202,11 @@ static inline unsigned char ra_code(char ch) {
   }
 }
 
-// Runs Raccess for `nseq` sequences; results go to the DEVICE arrays d_acc / d_cond, which the
-// caller has zero-filled, laid out with `offsets` (sequence i at offsets[i] - offsets[0]).
-// Sequences are processed longest first in chunks that fit the workspace budget.
-int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_t *offsets, int W, int delta,
-                      float *d_acc, float *d_cond) {
+// Runs Raccess for `nseq` sequences (sequence i = seqs[in_off[i] .. in_off[i] + lens[i]));
+// results go to the DEVICE arrays d_acc / d_cond, which the caller has zero-filled, sequence i
+// at out_off[i].  Sequences are processed longest first in chunks that fit the workspace budget.
+int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_t *in_off, const int32_t *lens,
+                      const int64_t *out_off, int W, int delta, float *d_acc, float *d_cond) {
   if (W < 1 || delta < 2 || W > kRaMaxSpan || W - delta > 128 || W + 2 >= RaSmallLayout::kHairpinN) {
     set_error("unsupported (maximal span, min accessible length): need 2 <= delta, W <= 129, W - delta <= 128");
     return PRB_ERR_ARG;
@@ -214,7 +214,7 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
   PRB_HIP(hipSetDevice(ctx->device));
   std::vector<int32_t> order(nseq);
   std::iota(order.begin(), order.end(), 0);
-  auto len = [&](int i) { return (int64_t)(offsets[i + 1] - offsets[i]); };
+  auto len = [&](int i) { return (int64_t)lens[i]; };
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len(a) > len(b); });
   int32_t pos = 0;
   std::vector<RaSeqDesc> desc;
@@ -226,24 +226,20 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
     int32_t end = pos;
     while (end < nseq) {
       const int64_t L = len(order[end]);
-      if (L > INT32_MAX - 4) {
-        set_error("sequence too long");
-        return PRB_ERR_ARG;
-      }
       const size_t need = (size_t)(band + ra_band_elems((int)L, W) + vec + ra_vec_elems((int)L)) * sizeof(double);
       if (end > pos && need > ctx->ra_budget_bytes) break;
       RaSeqDesc d;
       d.band_off = band;
       d.vec_off = vec;
       d.code_off = (int64_t)codes.size();
-      d.out_off = offsets[order[end]] - offsets[0];
+      d.out_off = out_off[order[end]];
       d.L = (int32_t)L;
       d.pad = 0;
       desc.push_back(d);
       band += ra_band_elems((int)L, W);
       vec += ra_vec_elems((int)L);
       codes.push_back(0);
-      const char *sp = seqs + offsets[order[end]];
+      const char *sp = seqs + in_off[order[end]];
       for (int64_t k = 0; k < L; k++) codes.push_back(ra_code(sp[k]));
       codes.push_back(0);
       end++;
@@ -292,8 +288,18 @@ extern "C" int prb_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, c
   if ((rc = ctx->ra_cond.ensure(bytes))) return rc;
   PRB_HIP(hipMemsetAsync(ctx->ra_acc.p, 0, bytes, ctx->stream));
   PRB_HIP(hipMemsetAsync(ctx->ra_cond.p, 0, bytes, ctx->stream));
-  if ((rc = run_accessibility(ctx, nseq, seqs, offsets, maximal_span, min_accessible_length, ctx->ra_acc.as<float>(),
-                              ctx->ra_cond.as<float>())))
+  std::vector<int32_t> lens(nseq);
+  std::vector<int64_t> out_off(nseq);
+  for (int32_t i = 0; i < nseq; i++) {
+    if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > INT32_MAX - 4) {
+      set_error("prb_accessibility: bad offsets");
+      return PRB_ERR_ARG;
+    }
+    lens[i] = (int32_t)(offsets[i + 1] - offsets[i]);
+    out_off[i] = offsets[i] - offsets[0];
+  }
+  if ((rc = run_accessibility(ctx, nseq, seqs, offsets, lens.data(), out_off.data(), maximal_span,
+                              min_accessible_length, ctx->ra_acc.as<float>(), ctx->ra_cond.as<float>())))
     return rc;
   PRB_HIP(hipMemcpyAsync(acc, ctx->ra_acc.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   PRB_HIP(hipMemcpyAsync(cond, ctx->ra_cond.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

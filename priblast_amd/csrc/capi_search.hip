@@ -1,8 +1,838 @@
-// C ABI, part 2: database pages, query batches and the search stages (being built).
+// C ABI, part 2: database pages, query batches and the search stages
+// (SearchSeed / ExtendWithoutGap / ExtendWithGap, rna_interaction_search.cpp:264-320).
+#include <omp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include <rocprim/rocprim.hpp>
+
 #include "../../include/priblast_hip.h"
 #include "context.hpp"
+#include "db_format.hpp"
+#include "encoder.hpp"
+#include "search_kernels.hpp"
+#include "seed_dfs.hpp"
+#include "suffix_array.hpp"
+
+namespace prb {
+int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_t *in_off, const int32_t *lens,
+                      const int64_t *out_off, int W, int delta, float *d_acc, float *d_cond);
+
+struct SearchConstMem {
+  DevBuf ints, bulge;
+  SearchConst view{};
+};
+
+struct PageMem {
+  DevBuf seqs, sa, start_pos, seq_length, acc, cond;
+  PageDev view{};
+};
+
+// buffers reused across prb_search_page calls
+struct SearchWs {
+  DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
+      state, keep, pending, surv, count, first, gapScratch, overflow, subset, bpCount, bpOff, bpOut, scanTmp;
+  void release() {
+    for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
+                      &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
+                      &subset, &bpCount, &bpOff, &bpOut, &scanTmp})
+      b->release();
+  }
+};
+
+static HitSoA carve_hits(DevBuf &b, int64_t n) {
+  HitSoA h;
+  uint8_t *p = b.as<uint8_t>();
+  const size_t n8 = ((size_t)n + 1) & ~(size_t)1; // keep the double arrays 8-byte aligned
+  h.e_acc = reinterpret_cast<double *>(p);
+  h.e_hyb = h.e_acc + n8;
+  h.e_tot = h.e_hyb + n8;
+  int32_t *ip = reinterpret_cast<int32_t *>(h.e_tot + n8);
+  h.q_sp = ip;
+  h.db_sp = ip + n8;
+  h.q_len = ip + 2 * n8;
+  h.db_len = ip + 3 * n8;
+  h.db_id = ip + 4 * n8;
+  h.db_id_start = ip + 5 * n8;
+  h.query = ip + 6 * n8;
+  return h;
+}
+static size_t hits_bytes(int64_t n) { return (((size_t)n + 1) & ~(size_t)1) * kHitBytes + 64; }
+
+} // namespace prb
+
+using namespace prb;
+
+struct prb_db {
+  prb_ctx *ctx = nullptr;
+  DbHeader hdr;
+  std::vector<DbPage> pages;
+  std::vector<PageMem> mem;
+};
+
+struct prb_qbatch {
+  prb_ctx *ctx = nullptr;
+  int32_t nq = 0, repeat_flag = 0;
+  std::vector<int64_t> off; // nq + 1; query q occupies [off[q], off[q] + len[q] + 1)
+  std::vector<int32_t> len, len_unmasked;
+  std::vector<char> seqs;   // same offsets, NUL after each query
+  std::vector<uint8_t> enc;
+  std::vector<int32_t> sa;
+  DevBuf d_enc, d_sa, d_acc, d_cond, d_off, d_len;
+  bool have_acc = false;
+  int32_t W = 0, delta = 0;
+  QBatchDev view{};
+};
+
+struct prb_hitset {
+  std::vector<prb_hit> hits;
+  std::vector<int32_t> bp;
+  int64_t counts[3] = {0, 0, 0};
+};
+
+namespace prb {
+static SearchWs &ws_of(prb_ctx *ctx) {
+  if (!ctx->search_ws) ctx->search_ws = new SearchWs();
+  return *static_cast<SearchWs *>(ctx->search_ws);
+}
+} // namespace prb
 
 extern "C" {
-int prb_search_const_upload(prb_ctx *) { return PRB_OK; }
-void prb_search_const_free(prb_ctx *) {}
+
+int prb_search_const_upload(prb_ctx *ctx) {
+  auto *m = new SearchConstMem();
+  ctx->search_const = m;
+  const EnergyParams &p = ctx->params;
+  std::vector<int32_t> ints;
+  auto add = [&](const int *src, size_t n) {
+    size_t at = ints.size();
+    ints.insert(ints.end(), src, src + n);
+    return at;
+  };
+  const size_t o_stack = add(&p.stack37[0][0], 49), o_int = add(p.internal37, 31), o_mm = add(&p.mismatchI37[0][0][0], 175),
+               o_11 = add(&p.int11_37[0][0][0][0], 1600), o_21 = add(&p.int21_37[0][0][0][0][0], 8000),
+               o_22 = add(&p.int22_37[0][0][0][0][0][0], 40000), o_d5 = add(&p.dangle5_37[0][0], 40),
+               o_d3 = add(&p.dangle3_37[0][0], 40);
+  std::vector<double> bulge(64);
+  for (int u = 0; u < 64; u++) // gapped_extension.cpp:439
+    bulge[u] = u <= 30 ? (double)p.bulge37[u] : p.bulge37[30] + p.lxc37 * std::log(u / 30.);
+  int rc;
+  if ((rc = m->ints.ensure(ints.size() * 4))) return rc;
+  if ((rc = m->bulge.ensure(bulge.size() * 8))) return rc;
+  PRB_HIP(hipMemcpy(m->ints.p, ints.data(), ints.size() * 4, hipMemcpyHostToDevice));
+  PRB_HIP(hipMemcpy(m->bulge.p, bulge.data(), bulge.size() * 8, hipMemcpyHostToDevice));
+  const int32_t *b = m->ints.as<int32_t>();
+  SearchConst &v = m->view;
+  v.stack37 = b + o_stack;
+  v.internal37 = b + o_int;
+  v.mismatchI37 = b + o_mm;
+  v.int11 = b + o_11;
+  v.int21 = b + o_21;
+  v.int22 = b + o_22;
+  v.dangle5 = b + o_d5;
+  v.dangle3 = b + o_d3;
+  v.bulge = m->bulge.as<double>();
+  v.terminal_au = p.terminal_au;
+  for (int a = 0; a < 5; a++)
+    for (int c = 0; c < 5; c++) v.bp_pair[a * 5 + c] = (unsigned char)p.bp_pair[a][c];
+  for (int t = 0; t < 7; t++) v.rtype[t] = (unsigned char)p.rtype[t];
+  v.rtype[7] = 0;
+  return PRB_OK;
 }
+
+void prb_search_const_free(prb_ctx *ctx) {
+  if (ctx->search_const) {
+    auto *m = static_cast<SearchConstMem *>(ctx->search_const);
+    m->ints.release();
+    m->bulge.release();
+    delete m;
+    ctx->search_const = nullptr;
+  }
+  if (ctx->search_ws) {
+    auto *w = static_cast<SearchWs *>(ctx->search_ws);
+    w->release();
+    delete w;
+    ctx->search_ws = nullptr;
+  }
+}
+
+// ------------------------------------------------------------------------ database
+static int upload_page(prb_ctx *ctx, const DbPage &pg, PageMem &m) {
+  int rc;
+  auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+    if ((rc = b.ensure(std::max<size_t>(bytes, 16)))) return rc;
+    if (bytes) PRB_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PRB_OK;
+  };
+  if ((rc = up(m.seqs, pg.seqs.data(), pg.seqs.size()))) return rc;
+  if ((rc = up(m.sa, pg.sa.data(), pg.sa.size() * 4))) return rc;
+  if ((rc = up(m.start_pos, pg.start_pos.data(), pg.start_pos.size() * 4))) return rc;
+  if ((rc = up(m.seq_length, pg.seq_length.data(), pg.seq_length.size() * 4))) return rc;
+  if ((rc = up(m.acc, pg.acc.data(), pg.acc.size() * 4))) return rc;
+  if ((rc = up(m.cond, pg.cond.data(), pg.cond.size() * 4))) return rc;
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  m.view.seqs = m.seqs.as<uint8_t>();
+  m.view.sa = m.sa.as<int32_t>();
+  m.view.start_pos = m.start_pos.as<int32_t>();
+  m.view.seq_length = m.seq_length.as<int32_t>();
+  m.view.acc = m.acc.as<float>();
+  m.view.cond = m.cond.as<float>();
+  m.view.nchars = (int32_t)pg.seqs.size();
+  m.view.nseq = pg.nseq;
+  return PRB_OK;
+}
+
+int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
+  if (!ctx || !prefix || !out) return PRB_ERR_ARG;
+  *out = nullptr;
+  auto *db = new prb_db();
+  db->ctx = ctx;
+  std::string err = read_db(prefix, db->hdr, db->pages);
+  if (!err.empty()) {
+    set_error(err);
+    delete db;
+    return PRB_ERR_IO;
+  }
+  PRB_HIP(hipSetDevice(ctx->device));
+  db->mem.resize(db->pages.size());
+  for (size_t i = 0; i < db->pages.size(); i++) {
+    int rc = upload_page(ctx, db->pages[i], db->mem[i]);
+    if (rc) {
+      prb_db_close(db);
+      return rc;
+    }
+  }
+  *out = db;
+  return PRB_OK;
+}
+
+void prb_db_close(prb_db *db) {
+  if (!db) return;
+  for (auto &m : db->mem)
+    for (DevBuf *b : {&m.seqs, &m.sa, &m.start_pos, &m.seq_length, &m.acc, &m.cond}) b->release();
+  delete db;
+}
+
+int prb_db_info(const prb_db *db, int32_t *hash_size, int32_t *repeat_flag, int32_t *maximal_span,
+                int32_t *min_accessible_length, int32_t *npages) {
+  if (!db) return PRB_ERR_ARG;
+  if (hash_size) *hash_size = db->hdr.hash_size;
+  if (repeat_flag) *repeat_flag = db->hdr.repeat_flag;
+  if (maximal_span) *maximal_span = db->hdr.maximal_span;
+  if (min_accessible_length) *min_accessible_length = db->hdr.min_accessible_length;
+  if (npages) *npages = (int32_t)db->pages.size();
+  return PRB_OK;
+}
+
+int prb_db_page_info(const prb_db *db, int32_t page, int32_t *nseq, int64_t *nchars) {
+  if (!db || page < 0 || page >= (int32_t)db->pages.size()) return PRB_ERR_ARG;
+  if (nseq) *nseq = db->pages[page].nseq;
+  if (nchars) *nchars = (int64_t)db->pages[page].seqs.size();
+  return PRB_OK;
+}
+
+const char *prb_db_seq_name(const prb_db *db, int32_t page, int32_t id) {
+  if (!db || page < 0 || page >= (int32_t)db->pages.size()) return nullptr;
+  const DbPage &pg = db->pages[page];
+  if (id < 0 || id >= pg.nseq) return nullptr;
+  return pg.names[id].c_str();
+}
+
+int prb_db_seq_lengths(const prb_db *db, int32_t page, int32_t id, int32_t *length, int32_t *length_unmasked,
+                       int32_t *start_pos) {
+  if (!db || page < 0 || page >= (int32_t)db->pages.size()) return PRB_ERR_ARG;
+  const DbPage &pg = db->pages[page];
+  if (id < 0 || id >= pg.nseq) return PRB_ERR_ARG;
+  if (length) *length = pg.seq_length[id];
+  if (length_unmasked) *length_unmasked = pg.seq_length_rep[id];
+  if (start_pos) *start_pos = pg.start_pos[id];
+  return PRB_OK;
+}
+
+// DbConstruction::Run (db_construction.cpp:37-83) as a tool: accessibilities on the GPU
+// (the same Raccess kernels as for queries), suffix array and k-mer table on the host.
+int prb_db_build(prb_ctx *ctx, const char *prefix, int32_t nseq, const char *const *names, const char *seqs,
+                 const int64_t *offsets, int32_t repeat_flag, int32_t hash_size, int32_t maximal_span,
+                 int32_t min_accessible_length, int32_t page_size) {
+  if (!ctx || !prefix || nseq <= 0 || !names || !seqs || !offsets || repeat_flag < 0 || repeat_flag > 2 ||
+      hash_size < 1 || hash_size > 12 || page_size < 1) {
+    set_error("prb_db_build: bad argument");
+    return PRB_ERR_ARG;
+  }
+  const int64_t total = offsets[nseq] - offsets[0];
+  std::vector<float> acc((size_t)std::max<int64_t>(total, 1)), cond((size_t)std::max<int64_t>(total, 1));
+  int rc = prb_accessibility(ctx, nseq, seqs, offsets, maximal_span, min_accessible_length, acc.data(), cond.data());
+  if (rc) return rc;
+  DbHeader hdr{hash_size, repeat_flag, maximal_span, min_accessible_length};
+  DbWriter w;
+  std::string err = w.open(prefix, hdr);
+  if (!err.empty()) {
+    set_error(err);
+    return PRB_ERR_IO;
+  }
+  Encoder enc(repeat_flag);
+  for (int32_t first = 0; first < nseq; first += page_size) {
+    const int32_t n = std::min(page_size, nseq - first);
+    DbPage pg;
+    pg.nseq = n;
+    int64_t t = 0;
+    for (int32_t k = 0; k < n; k++) {
+      const int32_t i = first + k;
+      const int64_t L = offsets[i + 1] - offsets[i];
+      pg.seq_length.push_back((int32_t)L);
+      pg.start_pos.push_back((int32_t)t);
+      t += L + 1;
+      enc.append_db(seqs + offsets[i], L, pg.seqs);
+      pg.names.push_back(names[i]);
+      // the file stores cond[0..delta) = 0 and the conditional value of window i at i+delta
+      // (raccess.cpp:462-480): the in-memory layout of stage 1 already has that shape
+      pg.acc.insert(pg.acc.end(), acc.begin() + (offsets[i] - offsets[0]), acc.begin() + (offsets[i + 1] - offsets[0]));
+      pg.cond.insert(pg.cond.end(), cond.begin() + (offsets[i] - offsets[0]), cond.begin() + (offsets[i + 1] - offsets[0]));
+    }
+    if (t > INT32_MAX) {
+      set_error("database page exceeds 2^31 characters: use a smaller page size");
+      return PRB_ERR_ARG;
+    }
+    pg.sa.resize(pg.seqs.size());
+    suffix_array(pg.seqs.data(), (int32_t)pg.seqs.size(), pg.sa.data());
+    build_kmer_table(pg.seqs, pg.sa, hash_size, pg.start_hash, pg.end_hash);
+    err = w.append_page(pg, min_accessible_length);
+    if (!err.empty()) {
+      set_error(err);
+      return PRB_ERR_IO;
+    }
+  }
+  return PRB_OK;
+}
+
+// -------------------------------------------------------------------- query batches
+int prb_qbatch_create(prb_ctx *ctx, int32_t nq, const char *seqs, const int64_t *offsets, int32_t repeat_flag,
+                      prb_qbatch **out) {
+  if (!ctx || nq <= 0 || !seqs || !offsets || !out || repeat_flag < 0 || repeat_flag > 2) {
+    set_error("prb_qbatch_create: bad argument");
+    return PRB_ERR_ARG;
+  }
+  *out = nullptr;
+  auto *qb = new prb_qbatch();
+  qb->ctx = ctx;
+  qb->nq = nq;
+  qb->repeat_flag = repeat_flag;
+  qb->off.resize(nq + 1);
+  qb->len.resize(nq);
+  qb->len_unmasked.resize(nq);
+  int64_t t = 0;
+  for (int32_t q = 0; q < nq; q++) {
+    const int64_t L = offsets[q + 1] - offsets[q];
+    if (L < 0 || L > (1 << 30)) {
+      delete qb;
+      set_error("prb_qbatch_create: bad offsets");
+      return PRB_ERR_ARG;
+    }
+    qb->off[q] = t;
+    qb->len[q] = (int32_t)L;
+    t += L + 1;
+  }
+  qb->off[nq] = t;
+  qb->seqs.assign((size_t)t, 0);
+  qb->enc.assign((size_t)t, 0);
+  qb->sa.assign((size_t)t, 0);
+  Encoder enc(repeat_flag);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int32_t q = 0; q < nq; q++) {
+    const int64_t o = qb->off[q];
+    const int32_t L = qb->len[q];
+    std::memcpy(qb->seqs.data() + o, seqs + offsets[q], (size_t)L);
+    enc.encode_query(seqs + offsets[q], L, qb->enc.data() + o);
+    suffix_array(qb->enc.data() + o, L + 1, qb->sa.data() + o);
+    int32_t c = 0;
+    for (int32_t k = 0; k <= L; k++) c += qb->enc[o + k] >= 2 && qb->enc[o + k] <= 5; // rna_interaction_search.cpp:179-183
+    qb->len_unmasked[q] = c;
+  }
+  PRB_HIP(hipSetDevice(ctx->device));
+  int rc = 0;
+  const size_t n = (size_t)t;
+  if ((rc = qb->d_enc.ensure(n)) || (rc = qb->d_sa.ensure(n * 4)) || (rc = qb->d_acc.ensure(n * 4)) ||
+      (rc = qb->d_cond.ensure(n * 4)) || (rc = qb->d_off.ensure((size_t)(nq + 1) * 8)) ||
+      (rc = qb->d_len.ensure((size_t)nq * 4))) {
+    prb_qbatch_destroy(qb);
+    return rc;
+  }
+  PRB_HIP(hipMemcpyAsync(qb->d_enc.p, qb->enc.data(), n, hipMemcpyHostToDevice, ctx->stream));
+  PRB_HIP(hipMemcpyAsync(qb->d_sa.p, qb->sa.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  PRB_HIP(hipMemcpyAsync(qb->d_off.p, qb->off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  PRB_HIP(hipMemcpyAsync(qb->d_len.p, qb->len.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+  PRB_HIP(hipMemsetAsync(qb->d_acc.p, 0, n * 4, ctx->stream));
+  PRB_HIP(hipMemsetAsync(qb->d_cond.p, 0, n * 4, ctx->stream));
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  qb->view.enc = qb->d_enc.as<uint8_t>();
+  qb->view.sa = qb->d_sa.as<int32_t>();
+  qb->view.acc = qb->d_acc.as<float>();
+  qb->view.cond = qb->d_cond.as<float>();
+  qb->view.off = qb->d_off.as<int64_t>();
+  qb->view.len = qb->d_len.as<int32_t>();
+  qb->view.nq = nq;
+  *out = qb;
+  return PRB_OK;
+}
+
+void prb_qbatch_destroy(prb_qbatch *qb) {
+  if (!qb) return;
+  for (DevBuf *b : {&qb->d_enc, &qb->d_sa, &qb->d_acc, &qb->d_cond, &qb->d_off, &qb->d_len}) b->release();
+  delete qb;
+}
+
+int prb_qbatch_accessibility(prb_ctx *ctx, prb_qbatch *qb, int32_t maximal_span, int32_t min_accessible_length) {
+  if (!ctx || !qb || qb->ctx != ctx) return PRB_ERR_ARG;
+  const size_t n = (size_t)qb->off[qb->nq];
+  PRB_HIP(hipSetDevice(ctx->device));
+  PRB_HIP(hipMemsetAsync(qb->d_acc.p, 0, n * 4, ctx->stream));
+  PRB_HIP(hipMemsetAsync(qb->d_cond.p, 0, n * 4, ctx->stream));
+  int rc = run_accessibility(ctx, qb->nq, qb->seqs.data(), qb->off.data(), qb->len.data(), qb->off.data(), maximal_span,
+                             min_accessible_length, qb->d_acc.as<float>(), qb->d_cond.as<float>());
+  if (rc) return rc;
+  qb->have_acc = true;
+  qb->W = maximal_span;
+  qb->delta = min_accessible_length;
+  return PRB_OK;
+}
+
+int prb_qbatch_get(prb_qbatch *qb, int32_t q, uint8_t *enc, int32_t *sa, float *acc, float *cond) {
+  if (!qb || q < 0 || q >= qb->nq) return PRB_ERR_ARG;
+  const int64_t o = qb->off[q];
+  const int32_t L = qb->len[q];
+  if (enc) std::memcpy(enc, qb->enc.data() + o, (size_t)L + 1);
+  if (sa) std::memcpy(sa, qb->sa.data() + o, ((size_t)L + 1) * 4);
+  if (acc || cond) {
+    if (!qb->have_acc) {
+      set_error("prb_qbatch_get: accessibilities not computed yet");
+      return PRB_ERR_STATE;
+    }
+    PRB_HIP(hipSetDevice(qb->ctx->device));
+    if (acc && L) PRB_HIP(hipMemcpy(acc, qb->d_acc.as<float>() + o, (size_t)L * 4, hipMemcpyDeviceToHost));
+    if (cond && L) PRB_HIP(hipMemcpy(cond, qb->d_cond.as<float>() + o, (size_t)L * 4, hipMemcpyDeviceToHost));
+  }
+  return PRB_OK;
+}
+
+int32_t prb_qbatch_length_unmasked(const prb_qbatch *qb, int32_t q) {
+  if (!qb || q < 0 || q >= qb->nq) return -1;
+  return qb->len_unmasked[q];
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------- search
+namespace prb {
+
+// Sorts `in` (n hits) into `out` by the reference's comparator made total:
+// (query, db_sp asc, q_sp asc, db_len desc, q_len desc, energy asc, input order);
+// LSD: one stable radix sort per key, least significant first.  perm_out[i] = index in `in`.
+static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &in, HitSoA out, int64_t n, int nq, uint32_t **perm_out) {
+  int rc;
+  const size_t N = (size_t)n;
+  if ((rc = w.kE.ensure(N * 8)) || (rc = w.kL.ensure(N * 4)) || (rc = w.kQ.ensure(N * 4)) || (rc = w.kP.ensure(N * 8)) ||
+      (rc = w.kTmp.ensure(N * 8)) || (rc = w.kTmp2.ensure(N * 8)) || (rc = w.idxA.ensure(N * 4)) ||
+      (rc = w.idxB.ensure(N * 4)))
+    return rc;
+  PRB_HIP(launch_make_keys(in, n, w.kE.as<uint64_t>(), w.kL.as<uint32_t>(), w.kQ.as<uint32_t>(), w.kP.as<uint64_t>(),
+                           w.idxA.as<uint32_t>(), ctx->stream));
+  uint32_t *ia = w.idxA.as<uint32_t>(), *ib = w.idxB.as<uint32_t>();
+  auto sort64 = [&](const uint64_t *keys, unsigned bits) -> int {
+    size_t tmp = 0;
+    PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys, w.kTmp2.as<uint64_t>(), ia, ib, N, 0, bits, ctx->stream));
+    if ((rc = w.sortTmp.ensure(tmp))) return rc;
+    PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, keys, w.kTmp2.as<uint64_t>(), ia, ib, N, 0, bits, ctx->stream));
+    std::swap(ia, ib);
+    return PRB_OK;
+  };
+  auto sort32 = [&](const uint32_t *keys, unsigned bits) -> int {
+    size_t tmp = 0;
+    PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys, w.kTmp2.as<uint32_t>(), ia, ib, N, 0, bits, ctx->stream));
+    if ((rc = w.sortTmp.ensure(tmp))) return rc;
+    PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, keys, w.kTmp2.as<uint32_t>(), ia, ib, N, 0, bits, ctx->stream));
+    std::swap(ia, ib);
+    return PRB_OK;
+  };
+  if ((rc = sort64(w.kE.as<uint64_t>(), 64))) return rc; // keys already in input order
+  PRB_HIP(launch_gather_u32(w.kL.as<uint32_t>(), ia, w.kTmp.as<uint32_t>(), n, ctx->stream));
+  if ((rc = sort32(w.kTmp.as<uint32_t>(), 32))) return rc;
+  PRB_HIP(launch_gather_u32(w.kQ.as<uint32_t>(), ia, w.kTmp.as<uint32_t>(), n, ctx->stream));
+  if ((rc = sort32(w.kTmp.as<uint32_t>(), 32))) return rc;
+  PRB_HIP(launch_gather_u64(w.kP.as<uint64_t>(), ia, w.kTmp.as<uint64_t>(), n, ctx->stream));
+  unsigned qbits = 1;
+  while ((1 << qbits) < nq && qbits < 31) qbits++;
+  if ((rc = sort64(w.kTmp.as<uint64_t>(), 32 + qbits))) return rc;
+  PRB_HIP(launch_gather_hits(in, ia, out, n, ctx->stream));
+  *perm_out = ia;
+  return PRB_OK;
+}
+
+struct ToI64 {
+  __host__ __device__ int64_t operator()(const int32_t &v) const { return (int64_t)v; }
+};
+struct MaxOp {
+  __host__ __device__ int64_t operator()(const int64_t &a, const int64_t &b) const { return a > b ? a : b; }
+};
+
+// CheckRedundancy on the sorted list `h`; writes the indices of the survivors (ascending) to
+// w.surv and returns their number.
+static int filter_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, double thr, int64_t *nsurv) {
+  int rc;
+  const size_t N = (size_t)n;
+  *nsurv = 0;
+  if (n == 0) return PRB_OK;
+  if ((rc = w.endKey.ensure(N * 8)) || (rc = w.pmax.ensure(N * 8)) || (rc = w.state.ensure(N)) || (rc = w.keep.ensure(N)) ||
+      (rc = w.pending.ensure(16)) || (rc = w.surv.ensure(N * 4)) || (rc = w.count.ensure(16)))
+    return rc;
+  PRB_HIP(launch_filter_init(h, n, thr, w.endKey.as<int64_t>(), w.state.as<uint8_t>(), ctx->stream));
+  size_t tmp = 0;
+  PRB_HIP(rocprim::inclusive_scan(nullptr, tmp, w.endKey.as<int64_t>(), w.pmax.as<int64_t>(), N, MaxOp(), ctx->stream));
+  if ((rc = w.scanTmp.ensure(tmp))) return rc;
+  PRB_HIP(rocprim::inclusive_scan(w.scanTmp.p, tmp, w.endKey.as<int64_t>(), w.pmax.as<int64_t>(), N, MaxOp(), ctx->stream));
+  for (int round = 0;; round++) {
+    PRB_HIP(hipMemsetAsync(w.pending.p, 0, 4, ctx->stream));
+    PRB_HIP(launch_filter_round(h, n, w.pmax.as<int64_t>(), w.state.as<uint8_t>(), w.pending.as<int32_t>(), ctx->stream));
+    int32_t pend = 0;
+    PRB_HIP(hipMemcpyAsync(&pend, w.pending.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    if (!pend) break;
+    if (round > 100000) {
+      set_error("redundancy filter did not converge");
+      return PRB_ERR_STATE;
+    }
+  }
+  PRB_HIP(launch_filter_final(h, n, w.pmax.as<int64_t>(), w.state.as<uint8_t>(), w.keep.as<uint8_t>(), ctx->stream));
+  tmp = 0;
+  rocprim::counting_iterator<uint32_t> iota(0);
+  PRB_HIP(rocprim::select(nullptr, tmp, iota, w.keep.as<uint8_t>(), w.surv.as<uint32_t>(), w.count.as<size_t>(), N,
+                          ctx->stream));
+  if ((rc = w.scanTmp.ensure(tmp))) return rc;
+  PRB_HIP(rocprim::select(w.scanTmp.p, tmp, iota, w.keep.as<uint8_t>(), w.surv.as<uint32_t>(), w.count.as<size_t>(), N,
+                          ctx->stream));
+  size_t cnt = 0;
+  PRB_HIP(hipMemcpyAsync(&cnt, w.count.p, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  *nsurv = (int64_t)cnt;
+  return PRB_OK;
+}
+
+static int download_hits(prb_ctx *ctx, const HitSoA &h, int64_t n, std::vector<prb_hit> &out) {
+  const size_t base = out.size();
+  out.resize(base + (size_t)n);
+  if (n == 0) return PRB_OK;
+  std::vector<int32_t> iv((size_t)n);
+  std::vector<double> dv((size_t)n);
+  auto geti = [&](const int32_t *src, int32_t prb_hit::*f) -> int {
+    PRB_HIP(hipMemcpy(iv.data(), src, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) out[base + i].*f = iv[i];
+    return PRB_OK;
+  };
+  auto getd = [&](const double *src, double prb_hit::*f) -> int {
+    PRB_HIP(hipMemcpy(dv.data(), src, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) out[base + i].*f = dv[i];
+    return PRB_OK;
+  };
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = geti(h.q_sp, &prb_hit::q_sp)) || (rc = geti(h.db_sp, &prb_hit::db_sp)) || (rc = geti(h.q_len, &prb_hit::q_len)) ||
+      (rc = geti(h.db_len, &prb_hit::db_len)) || (rc = geti(h.db_id, &prb_hit::db_id)) ||
+      (rc = geti(h.db_id_start, &prb_hit::db_id_start)) || (rc = geti(h.query, &prb_hit::query)) ||
+      (rc = getd(h.e_acc, &prb_hit::e_acc)) || (rc = getd(h.e_hyb, &prb_hit::e_hyb)) || (rc = getd(h.e_tot, &prb_hit::e_tot)))
+    return rc;
+  for (int64_t i = 0; i < n; i++) {
+    out[base + i].bp_count = 0;
+    out[base + i].bp_offset = 0;
+  }
+  return PRB_OK;
+}
+
+// all stages for the queries [q0, q1) of the batch against one page
+static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, const prb_ris_opts &opts, int last_stage,
+                        const std::vector<SeedCandidate> &cands_all, size_t c0, size_t c1, prb_hitset *hs) {
+  SearchWs &w = ws_of(ctx);
+  const SearchConst &sc = static_cast<SearchConstMem *>(ctx->search_const)->view;
+  const DbPage &pg = db->pages[page];
+  const PageDev &pd = db->mem[page].view;
+  const int delta = db->hdr.min_accessible_length;
+  ExtOpts eo{delta, opts.drop_out_wo_gap, opts.drop_out_w_gap, opts.min_helix_length};
+  int rc;
+  // ---- seeds: one row per (candidate, db SA entry) ----
+  const int32_t ncand = (int32_t)(c1 - c0);
+  if (ncand == 0) return PRB_OK;
+  std::vector<CandDev> cd((size_t)ncand);
+  int64_t nrows = 0;
+  for (int32_t i = 0; i < ncand; i++) {
+    const SeedCandidate &s = cands_all[c0 + i];
+    cd[i] = CandDev{s.sp_q, s.ep_q, s.sp_db, s.ep_db, s.length, s.query, s.score, nrows};
+    nrows += (int64_t)s.ep_db - s.sp_db + 1;
+  }
+  if ((rc = w.cands.ensure(cd.size() * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(nrows + 1) * 4)) ||
+      (rc = w.row_off.ensure((size_t)(nrows + 1) * 8)))
+    return rc;
+  PRB_HIP(hipMemcpyAsync(w.cands.p, cd.data(), cd.size() * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ctx->time_begin())) return rc;
+  // one extra zero entry so that the exclusive scan over nrows+1 values also yields the total
+  PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + nrows, 0, 4, ctx->stream));
+  PRB_HIP(launch_seed_count(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.row_count.as<int32_t>(), ctx->stream));
+  {
+    size_t tmp = 0;
+    auto in = rocprim::make_transform_iterator(w.row_count.as<int32_t>(), ToI64());
+    PRB_HIP(rocprim::exclusive_scan(nullptr, tmp, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nrows + 1,
+                                    rocprim::plus<int64_t>(), ctx->stream));
+    if ((rc = w.scanTmp.ensure(tmp))) return rc;
+    PRB_HIP(rocprim::exclusive_scan(w.scanTmp.p, tmp, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nrows + 1,
+                                    rocprim::plus<int64_t>(), ctx->stream));
+  }
+  int64_t nseed = 0;
+  PRB_HIP(hipMemcpyAsync(&nseed, w.row_off.as<int64_t>() + nrows, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  hs->counts[0] += nseed;
+  if (nseed == 0) return ctx->time_end("seed", 2);
+  if (nseed > (int64_t)UINT32_MAX - 16) {
+    set_error("too many seed hits in one sub-batch: lower PRB_SEARCH_PAIRS");
+    return PRB_ERR_NOMEM;
+  }
+  if ((rc = w.hitsA.ensure(hits_bytes(nseed)))) return rc;
+  HitSoA A = carve_hits(w.hitsA, nseed);
+  PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.row_off.as<int64_t>(), A, ctx->stream));
+  if ((rc = ctx->time_end("seed", 2))) return rc;
+  if (last_stage == 1) return download_hits(ctx, A, nseed, hs->hits);
+
+  // ---- ungapped extension, sort, redundancy filter ----
+  if ((rc = ctx->time_begin())) return rc;
+  PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, ctx->stream));
+  if ((rc = ctx->time_end("ungapped", 1))) return rc;
+  if ((rc = w.hitsB.ensure(hits_bytes(nseed)))) return rc;
+  HitSoA B = carve_hits(w.hitsB, nseed);
+  uint32_t *perm = nullptr;
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = sort_hits(ctx, w, A, B, nseed, qb->nq, &perm))) return rc;
+  if ((rc = ctx->time_end("sort", 9))) return rc;
+  int64_t nung = 0;
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = filter_hits(ctx, w, B, nseed, opts.interaction_threshold, &nung))) return rc;
+  if ((rc = ctx->time_end("filter", 3))) return rc;
+  hs->counts[1] += nung;
+  if (nung == 0) return PRB_OK;
+  // compact survivors into A (A's seed content is no longer needed)
+  HitSoA U = carve_hits(w.hitsA, nung);
+  PRB_HIP(launch_gather_hits(B, w.surv.as<uint32_t>(), U, nung, ctx->stream));
+  if ((rc = w.first.ensure((size_t)nung))) return rc;
+  PRB_HIP(launch_mark_first(U.query, nung, w.first.as<uint8_t>(), ctx->stream));
+  if (last_stage == 2) {
+    const size_t base = hs->hits.size();
+    if ((rc = download_hits(ctx, U, nung, hs->hits))) return rc;
+    // GetBasePair (rna_interaction_search.cpp:371-385): complementary positions of the diagonal
+    for (size_t i = base; i < hs->hits.size(); i++) {
+      prb_hit &h = hs->hits[i];
+      const uint8_t *qs = qb->enc.data() + qb->off[h.query];
+      h.bp_offset = (int64_t)hs->bp.size() / 2;
+      const int len = (int)(uint16_t)h.q_len;
+      for (int j = 0; j < len; j++)
+        if (ctx->params.bp_pair[qs[h.q_sp + j] - 1][pg.seqs[h.db_sp + j] - 1] != 0) {
+          hs->bp.push_back(h.q_sp + j);
+          hs->bp.push_back(h.db_sp + j);
+          h.bp_count++;
+        }
+    }
+    return PRB_OK;
+  }
+
+  // ---- gapped extension ----
+  if ((rc = w.hitsC.ensure(hits_bytes(nung)))) return rc;
+  HitSoA G = carve_hits(w.hitsC, nung);
+  if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4))) return rc;
+  auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
+    const int64_t maxthreads = 256 * 768;
+    int64_t nt = std::min<int64_t>(((n + 255) / 256) * 256, maxthreads);
+    gs.cap_diag = cap_diag;
+    gs.cap_rec = cap_rec;
+    gs.bytes_per_thread = (size_t)cap_diag * 16 + (size_t)cap_rec * 16;
+    while (nt > 256 && (size_t)nt * gs.bytes_per_thread > ((size_t)6 << 30)) nt = ((nt / 2 + 255) / 256) * 256;
+    gs.nthreads = (int32_t)nt;
+    int r = w.gapScratch.ensure((size_t)nt * gs.bytes_per_thread);
+    gs.base = w.gapScratch.as<uint8_t>();
+    return r;
+  };
+  // runs `mode` over the hit list `subset` (or all n), growing the scratch for hits that overflow
+  // extends every hit of U into G, growing the scratch for the hits that overflow it
+  auto run_gapped = [&](int64_t n) -> int {
+    const uint32_t *subset = nullptr;
+    int cap_diag = 128, cap_rec = 320;
+    GapScratch gs;
+    if ((rc = scratch_for(n, cap_diag, cap_rec, gs))) return rc;
+    PRB_HIP(launch_gapped(U, G, n, subset, qb->view, pd, sc, eo, gs, 0, w.overflow.as<uint8_t>(), w.first.as<uint8_t>(),
+                          nullptr, nullptr, nullptr, ctx->stream));
+    // collect overflowed hits and retry with 4x the scratch until none is left
+    std::vector<uint8_t> ov((size_t)n);
+    std::vector<uint32_t> sub;
+    const uint32_t *cur = subset;
+    std::vector<uint32_t> cur_host;
+    int64_t cur_n = n;
+    for (;;) {
+      PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)cur_n, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      sub.clear();
+      for (int64_t i = 0; i < cur_n; i++)
+        if (ov[i]) sub.push_back(cur ? cur_host[i] : (uint32_t)i);
+      if (sub.empty()) break;
+      cap_diag *= 4;
+      cap_rec *= 4;
+      if (cap_diag > 32768) {
+        set_error("gapped extension exceeds the supported extension length (32768)");
+        return PRB_ERR_STATE;
+      }
+      if (cap_rec > 65535) cap_rec = 65535;
+      ctx->max_gap_caps = std::max(ctx->max_gap_caps, cap_diag);
+      cur_host = sub;
+      cur_n = (int64_t)sub.size();
+      PRB_HIP(hipMemcpyAsync(w.subset.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      cur = w.subset.as<uint32_t>();
+      if ((rc = scratch_for(cur_n, cap_diag, cap_rec, gs))) return rc;
+      PRB_HIP(launch_gapped(U, G, cur_n, cur, qb->view, pd, sc, eo, gs, 0, w.overflow.as<uint8_t>(), w.first.as<uint8_t>(),
+                            nullptr, nullptr, nullptr, ctx->stream));
+    }
+    return PRB_OK;
+  };
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = run_gapped(nung))) return rc;
+  if ((rc = ctx->time_end("gapped", 1))) return rc;
+
+  // ---- final sort + filter ----
+  HitSoA S = carve_hits(w.hitsB, nung);
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = sort_hits(ctx, w, G, S, nung, qb->nq, &perm))) return rc;
+  if ((rc = ctx->time_end("sort", 9))) return rc;
+  int64_t nfin = 0;
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = filter_hits(ctx, w, S, nung, opts.final_threshold, &nfin))) return rc;
+  if ((rc = ctx->time_end("filter", 3))) return rc;
+  hs->counts[2] += nfin;
+  if (nfin == 0) return PRB_OK;
+  // final hits, and for each the index of its pre-gapped state in U (for the traceback)
+  HitSoA F = carve_hits(w.hitsC, nfin); // G is dead after the sort
+  PRB_HIP(launch_gather_hits(S, w.surv.as<uint32_t>(), F, nfin, ctx->stream));
+  PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset.as<uint32_t>(), nfin, ctx->stream));
+  const size_t base = hs->hits.size();
+  if ((rc = download_hits(ctx, F, nfin, hs->hits))) return rc;
+
+  // ---- traceback of the survivors: re-run their extension, count then write base pairs ----
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = w.bpCount.ensure((size_t)(nfin + 1) * 4)) || (rc = w.bpOff.ensure((size_t)(nfin + 1) * 8))) return rc;
+  // scratch large enough for every hit of this list: the largest caps any hit needed so far
+  {
+    int cap_diag = std::max(128, ctx->max_gap_caps), cap_rec = std::min(65535, cap_diag / 128 * 320);
+    GapScratch gs;
+    if ((rc = scratch_for(nfin, cap_diag, cap_rec, gs))) return rc;
+    PRB_HIP(hipMemsetAsync(w.bpCount.p, 0, (size_t)(nfin + 1) * 4, ctx->stream));
+    PRB_HIP(launch_gapped(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, gs, 1, nullptr, w.first.as<uint8_t>(),
+                          w.bpCount.as<int32_t>(), nullptr, nullptr, ctx->stream));
+    std::vector<int32_t> cnt((size_t)nfin);
+    PRB_HIP(hipMemcpyAsync(cnt.data(), w.bpCount.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> off((size_t)nfin + 1, 0);
+    for (int64_t i = 0; i < nfin; i++) {
+      if (cnt[i] < 0) {
+        set_error("internal error: traceback scratch overflow");
+        return PRB_ERR_STATE;
+      }
+      off[i + 1] = off[i] + cnt[i];
+    }
+    const int64_t total = off[nfin];
+    if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
+    PRB_HIP(hipMemcpyAsync(w.bpOff.p, off.data(), (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    PRB_HIP(launch_gapped(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, gs, 2, nullptr, w.first.as<uint8_t>(),
+                          nullptr, w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
+    const size_t bp_base = hs->bp.size();
+    hs->bp.resize(bp_base + (size_t)total * 2);
+    if (total) PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpOut.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < nfin; i++) {
+      hs->hits[base + i].bp_count = cnt[i];
+      hs->hits[base + i].bp_offset = (int64_t)(bp_base / 2) + off[i];
+    }
+  }
+  return ctx->time_end("traceback", 2);
+}
+
+} // namespace prb
+
+extern "C" {
+
+int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, const prb_ris_opts *opts, int32_t last_stage,
+                    prb_hitset **out) {
+  if (!ctx || !qb || !db || !opts || !out || qb->ctx != ctx || db->ctx != ctx || page < 0 ||
+      page >= (int32_t)db->pages.size() || last_stage < 1 || last_stage > 3) {
+    set_error("prb_search_page: bad argument");
+    return PRB_ERR_ARG;
+  }
+  *out = nullptr;
+  if (!qb->have_acc || qb->W != db->hdr.maximal_span || qb->delta != db->hdr.min_accessible_length) {
+    set_error("prb_search_page: query accessibilities must be computed with the database's span / window parameters");
+    return PRB_ERR_STATE;
+  }
+  if (qb->repeat_flag != db->hdr.repeat_flag) {
+    set_error("prb_search_page: query batch was encoded with a different repeat flag than the database");
+    return PRB_ERR_STATE;
+  }
+  if (opts->drop_out_w_gap < 0 || opts->drop_out_w_gap > 30 || opts->drop_out_wo_gap < 1 || opts->drop_out_wo_gap > 15 ||
+      opts->min_helix_length < 1 || opts->max_seed_length < 1) {
+    set_error("unsupported option: need 0 <= -x <= 30, 1 <= -y <= 15 (beyond that the reference reads outside its "
+              "31-entry loop tables), -m >= 1, -l >= 1");
+    return PRB_ERR_ARG;
+  }
+  PRB_HIP(hipSetDevice(ctx->device));
+  const DbPage &pg = db->pages[page];
+  // seed search proper: DFS over the two suffix arrays, per query, on the host
+  std::vector<std::vector<SeedCandidate>> per_q((size_t)qb->nq);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int32_t q = 0; q < qb->nq; q++) {
+    seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
+             opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
+    for (auto &c : per_q[q]) c.query = q;
+  }
+  std::vector<SeedCandidate> cands;
+  std::vector<size_t> qstart((size_t)qb->nq + 1, 0);
+  std::vector<double> qpairs((size_t)qb->nq, 0);
+  for (int32_t q = 0; q < qb->nq; q++) {
+    qstart[q] = cands.size();
+    for (auto &c : per_q[q]) qpairs[q] += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
+    cands.insert(cands.end(), per_q[q].begin(), per_q[q].end());
+  }
+  qstart[qb->nq] = cands.size();
+  auto *hs = new prb_hitset();
+  const char *env = getenv("PRB_SEARCH_PAIRS");
+  const double budget = env ? atof(env) : 6.0e7;
+  int rc = PRB_OK;
+  for (int32_t q0 = 0; q0 < qb->nq && rc == PRB_OK;) {
+    int32_t q1 = q0;
+    double acc = 0;
+    while (q1 < qb->nq && (q1 == q0 || acc + qpairs[q1] <= budget)) acc += qpairs[q1++];
+    rc = search_range(ctx, qb, db, page, *opts, last_stage, cands, qstart[q0], qstart[q1], hs);
+    q0 = q1;
+  }
+  if (rc != PRB_OK) {
+    delete hs;
+    return rc;
+  }
+  *out = hs;
+  return PRB_OK;
+}
+
+int64_t prb_hitset_size(const prb_hitset *hs) { return hs ? (int64_t)hs->hits.size() : -1; }
+const prb_hit *prb_hitset_hits(const prb_hitset *hs) { return hs ? hs->hits.data() : nullptr; }
+const int32_t *prb_hitset_basepairs(const prb_hitset *hs, int64_t *count) {
+  if (!hs) return nullptr;
+  if (count) *count = (int64_t)hs->bp.size() / 2;
+  return hs->bp.data();
+}
+void prb_hitset_counts(const prb_hitset *hs, int64_t counts[3]) {
+  for (int i = 0; i < 3; i++) counts[i] = hs ? hs->counts[i] : 0;
+}
+void prb_hitset_free(prb_hitset *hs) { delete hs; }
+
+} // extern "C"

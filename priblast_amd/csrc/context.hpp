@@ -47,6 +47,8 @@ struct prb_ctx {
   prb::RaConst ra_const{};
   // int tables for the search stages (search_kernels.hip)
   void *search_const = nullptr;
+  void *search_ws = nullptr;   // prb::SearchWs, capi_search.hip
+  int max_gap_caps = 128;      // largest diagonal capacity any gapped extension has needed
   prb::DevBuf d_expd, d_log, d_small, d_big;
   // Raccess workspaces
   prb::DevBuf ra_band, ra_vec, ra_codes, ra_desc, ra_acc, ra_cond;

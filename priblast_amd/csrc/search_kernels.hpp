@@ -1,0 +1,104 @@
+// Host-visible interface of the interaction-search kernels (search_kernels.hip):
+// seed expansion, ungapped extension, sort + redundancy filter, gapped extension, traceback.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace prb {
+
+// Integer Turner tables (0.01 kcal/mol) as used by the extension stages
+// (ungapped_extension.cpp:157-186, gapped_extension.cpp:366-399, 426-473).
+struct SearchConst {
+  const int32_t *stack37;   // [7][7]
+  const int32_t *internal37; // [31]
+  const int32_t *mismatchI37; // [7][5][5]
+  const int32_t *int11;     // [8][8][5][5]
+  const int32_t *int21;     // [8][8][5][5][5]
+  const int32_t *int22;     // [8][8][5][5][5][5]
+  const int32_t *dangle5;   // [8][5]
+  const int32_t *dangle3;   // [8][5]
+  const double *bulge;      // [64]: bulge37[u] for u <= 30, logarithmic extrapolation beyond
+  int32_t terminal_au;
+  unsigned char bp_pair[25];
+  unsigned char rtype[8];
+};
+
+struct PageDev {
+  const uint8_t *seqs; // page text: reversed sequences, 0 after each
+  const int32_t *sa;
+  const int32_t *start_pos;
+  const int32_t *seq_length;
+  const float *acc;  // padded to L per sequence; sequence id at start_pos[id] - id
+  const float *cond;
+  int32_t nchars, nseq;
+};
+
+struct QBatchDev {
+  const uint8_t *enc;   // query q at off[q], L+1 codes (trailing 0)
+  const int32_t *sa;    // same offsets
+  const float *acc;     // same offsets (L values + one 0)
+  const float *cond;
+  const int64_t *off;
+  const int32_t *len;   // L
+  int32_t nq;
+};
+
+struct CandDev { // SeedCandidate + first row of the candidate (one row per db SA entry)
+  int32_t sp_q, ep_q, sp_db, ep_db, length, query;
+  double score;
+  int64_t row0;
+};
+
+struct HitSoA {
+  int32_t *q_sp, *db_sp, *q_len, *db_len, *db_id, *db_id_start, *query;
+  double *e_acc, *e_hyb, *e_tot;
+};
+constexpr int kHitInts = 7, kHitDoubles = 3;
+constexpr size_t kHitBytes = kHitInts * 4 + kHitDoubles * 8;
+
+struct ExtOpts {
+  int32_t delta;       // min accessible length
+  int32_t drop_wo_gap; // -y
+  int32_t drop_w_gap;  // -x
+  int32_t min_helix;   // -m
+};
+
+// ---- seeds ----
+hipError_t launch_seed_count(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb,
+                             const PageDev &pg, int delta, int32_t *row_count, hipStream_t s);
+hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb,
+                            const PageDev &pg, int delta, const int64_t *row_off, HitSoA hits, hipStream_t s);
+// ---- ungapped ----
+hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc,
+                           ExtOpts o, hipStream_t s);
+// ---- sort keys / gather ----
+hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, uint32_t *k_len, uint32_t *k_qsp,
+                            uint64_t *k_pos, uint32_t *idx, hipStream_t s);
+hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
+hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t *dst, int64_t n, hipStream_t s);
+hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
+hipError_t launch_mark_first(const int32_t *query, int64_t n, uint8_t *first, hipStream_t s);
+// ---- redundancy filter on a sorted list ----
+// state: 0 unknown, 1 active, 2 inactive; keep[i] = 1 for survivors
+hipError_t launch_filter_init(const HitSoA &h, int64_t n, double thr, int64_t *db_end_key, uint8_t *state, hipStream_t s);
+hipError_t launch_filter_round(const HitSoA &h, int64_t n, const int64_t *pmax, uint8_t *state, int32_t *pending,
+                               hipStream_t s);
+hipError_t launch_filter_final(const HitSoA &h, int64_t n, const int64_t *pmax, const uint8_t *state, uint8_t *keep,
+                               hipStream_t s);
+// ---- gapped ----
+struct GapScratch {
+  uint8_t *base;        // per-thread blocks
+  size_t bytes_per_thread;
+  int32_t cap_rec, cap_diag;
+  int32_t nthreads;     // resident threads (grid * block)
+};
+// mode 0: extend hits in place (coords + energies), overflow[i] = 1 if scratch was too small
+// mode 1: count base pairs of the final alignment into bp_count[i]
+// mode 2: write base pairs at bp_off[i]
+hipError_t launch_gapped(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
+                         const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
+                         uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
+                         int32_t *bp_out, hipStream_t s);
+
+} // namespace prb
