@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the `ris` hot path on MI355X (BASELINE.json metric: query RNAs/sec in `ris`).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE.json configs[1] - synthetic i.i.d. uniform A/C/G/U, 5,000
+queries of 1 kb (seed 2) against a 5,000 x 1 kb database (seed 1), reference defaults
+(W=70, delta=5, hash 8, -l 20 -e -6 -f -4 -g -8 -x 16 -y 5 -m 3).  The database is built once,
+untimed, by the library's own `db` path (GPU Raccess + host SA) in the reference's file format
+and kept resident in HBM.  A "step" is one batch of `--queries` consecutive queries per GPU
+through the whole hot path: Raccess -> seed search -> ungapped -> sort/filter -> gapped ->
+sort/filter -> traceback -> final hits on the host (N > 1: final hits gathered over RCCL).
+Weak scaling: every rank processes its own `--queries` per step.
+
+One JSON line is printed by rank 0 (contract in the task description) with
+  roofline     : dominant kernel (k_gapped) - algorithmic bytes = 600 B per post-ungapped hit
+                 (DESIGN.md "Measurement") / device time from HIP events on the
+                 library's stream, against the 8 TB/s HBM peak;
+  cpu_baseline : the unmodified reference (oracle/_ref/pRIblast.shipped, OpenMP over all host
+                 cores) on a bounded sample of the same queries and the same database files.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "traceback")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=int(os.environ.get("BENCH_QUERIES", 32)), help="queries per GPU per step")
+    ap.add_argument("--db-seqs", type=int, default=int(os.environ.get("BENCH_DB_SEQS", 5000)))
+    ap.add_argument("--length", type=int, default=int(os.environ.get("BENCH_LENGTH", 1000)))
+    ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("BENCH_CPU_QUERIES", -1)),
+                    help="queries in the CPU baseline sample (-1: sized for ~20 s; 0: skip)")
+    ap.add_argument("--workdir", default=os.environ.get("BENCH_WORKDIR", os.path.join(tempfile.gettempdir(), "priblast_bench")))
+    return ap.parse_args()
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(a, workdir, dbprefix, qnames, qseqs, log):
+    """Reference `ris` (shipped flags, OpenMP over all host cores) on the first queries."""
+    import gen_synthetic
+    cores = host_cores()
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.shipped")
+    # reference single-core cost: 0.43 ms/nt Raccess + 3.8 ns per (query nt x db nt)
+    per_query = a.length * 0.43e-3 + 3.8e-9 * a.length * (a.db_seqs * (a.length + 1))
+    n = a.cpu_queries if a.cpu_queries >= 0 else max(cores, int(20.0 * cores / per_query))
+    n = max(1, min(n, len(qseqs)))
+    if a.cpu_queries == 0:
+        return None
+    sample = os.path.join(workdir, f"cpu_sample_{n}.fa")
+    gen_synthetic.write_fasta(sample, zip(qnames[:n], qseqs[:n]))
+    out = os.path.join(workdir, "cpu_sample.out")
+    if os.path.exists(ref):
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+        t = time.time()
+        subprocess.run([ref, "ris", "-i", sample, "-o", out, "-d", dbprefix, "-a", "dynamic", "-p", workdir],
+                       check=True, env=env, cwd=workdir, stdout=subprocess.DEVNULL)
+        dt = time.time() - t
+        kind = "reference"
+    else:
+        import oraclelib
+        t = time.time()
+        oraclelib.ris(sample, dbprefix, out, nthreads=cores)
+        dt = time.time() - t
+        kind = "port"
+    with open(out) as f:
+        nhits = max(0, sum(1 for _ in f) - 3)
+    log(f"cpu baseline ({kind}): {n} queries in {dt:.1f} s on {cores} cores, {nhits} hits")
+    return {"value": n / dt, "unit": "queries/s", "cores": cores, "kind": kind,
+            "sample": f"first {n} of the {len(qseqs)} queries vs the full database, {nhits} result lines, {dt:.1f} s wall"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import gen_synthetic
+    from priblast_amd import capi, dist as pdist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    os.makedirs(a.workdir, exist_ok=True)
+    tag = f"s{a.db_seqs}x{a.length}"
+    dbprefix = os.path.join(a.workdir, f"db_{tag}")
+    nq_total = max(a.db_seqs, (a.steps + a.warmup) * a.queries * world)
+    qrecs = list(gen_synthetic.gen(nq_total, a.length, 2, "q"))
+    qnames, qseqs = [r[0] for r in qrecs], [r[1] for r in qrecs]
+
+    ctx = capi.Context(local)
+    t0 = time.time()
+    if rank == 0 and not all(os.path.exists(f"{dbprefix}.{e}") for e in ("bas", "seq", "acc", "nam", "ind")):
+        drecs = list(gen_synthetic.gen(a.db_seqs, a.length, 1, "db"))
+        capi.db_build(ctx, dbprefix + ".tmp", [r[0] for r in drecs], [r[1] for r in drecs], 0, 8, 70, 5)
+        for e in ("bas", "seq", "acc", "nam", "ind"):
+            os.replace(f"{dbprefix}.tmp.{e}", f"{dbprefix}.{e}")
+        ms, _ = ctx.stage_ms("raccess")
+        log(f"database built in {time.time() - t0:.1f} s (Raccess on the GPU: {ms / 1e3:.1f} s for {a.db_seqs} x {a.length} nt)")
+    barrier()
+    db = capi.Db(ctx, dbprefix)
+    opts = capi.default_opts()
+
+    def step(k):
+        """one batch of a.queries queries of this rank through the whole hot path"""
+        lo, hi = pdist.batch_slice(k, rank, world, a.queries)
+        qs = qseqs[lo:hi]
+        qb = capi.QBatch(ctx, qs, db.repeat_flag)
+        qb.accessibility(db.W, db.delta)
+        total = [0, 0, 0]
+        allhits = []
+        for page in range(db.npages):
+            hits, bp, counts = capi.search_page(ctx, qb, db, page, opts, 3)
+            allhits.append(hits)
+            for i in range(3):
+                total[i] += counts[i]
+        qb.close()
+        hits = np.concatenate(allhits) if allhits else np.zeros(0, capi.HIT_DTYPE)
+        if world > 1:  # final hit gather over RCCL: counts, then padded POD records
+            pdist.gather_hits(hits, 0, "cuda")
+        return total
+
+    for k in range(a.warmup):
+        step(k)
+    ctx.reset_timers()
+    barrier()
+    t = time.perf_counter()
+    counts = [0, 0, 0]
+    for k in range(a.warmup, a.warmup + a.steps):
+        c = step(k)
+        counts = [x + y for x, y in zip(counts, c)]
+    barrier()
+    dt = time.perf_counter() - t
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cc = torch.tensor(counts, device="cuda", dtype=torch.int64)
+        dist.all_reduce(cc)
+        allc = [int(x) for x in cc.tolist()]
+    else:
+        allc = counts
+    stage = {s: ctx.stage_ms(s) for s in STAGES}  # rank-local device time over the timed steps
+
+    if rank == 0:
+        nq = a.queries * a.steps * world
+        gap_ms, gap_launch = stage["gapped"]
+        gap_units = counts[1]  # post-ungapped hits this rank extended
+        achieved = (gap_units * GAPPED_BYTES_PER_HIT / 1e9) / (gap_ms / 1e3) if gap_ms > 0 else 0.0
+        res = {
+            "metric": "query RNAs/sec in `ris` step",
+            "value": nq / dt,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"ris: {a.queries} x {a.length} nt synthetic queries per GPU per step vs {a.db_seqs}-seq x "
+                                   f"{a.length} nt database (BASELINE configs[1] shape), full pipeline on the GPU",
+                       "queries_per_step_per_gpu": a.queries, "db_seqs": a.db_seqs, "length": a.length,
+                       "hits_per_step": {"seed": allc[0] // a.steps, "ungapped": allc[1] // a.steps, "final": allc[2] // a.steps},
+                       "parallelism": f"queries sharded over {world} GPU(s), final hits gathered over RCCL"},
+            "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
+            "roofline": {"bound": "hbm", "kernel": "k_gapped", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": gap_launch, "avg_launch_ms": gap_ms / max(gap_launch, 1),
+                         "units_per_launch": gap_units / max(gap_launch, 1), "bytes_per_unit": GAPPED_BYTES_PER_HIT},
+        }
+        if world == 1:
+            res["cpu_baseline"] = cpu_baseline(a, a.workdir, dbprefix, qnames, qseqs, log)
+        print(json.dumps(res), flush=True)
+    db.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

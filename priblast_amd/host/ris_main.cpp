@@ -1,0 +1,271 @@
+// pRIblast-hip: drop-in for the reference's `ris` sub-command on top of the C ABI.
+//
+// Command line, defaults, error texts and the output format follow the reference
+// (main.cpp:36-111, 148-175; rna_interaction_search_parameters.cpp:33-114;
+// rna_interaction_search.cpp:322-369, 445-476).  `-a` and `-p` are accepted and ignored: the
+// MPI/OpenMP query schedulers are replaced by batched GPU stages; queries are dealt in
+// batches to the GPUs named by PRB_DEVICES (default: device 0).
+#include <getopt.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/priblast_hip.h"
+#include "fasta.hpp"
+
+namespace {
+
+void usage() {
+  std::puts("pRIblast-hip - RNA-RNA interaction search (ris step of pRIblast) on AMD Instinct GPUs\n"
+            "\n"
+            "pRIblast-hip ris -i InputFastaFile -o OutputFileName -d DatabaseFileName\n"
+            "             [-l MaxSeedLength] [-e HybridizationEnergyThreshold] [-f InteractionEnergyThreshold]\n"
+            "             [-x DropOutLengthInGappedExtension] [-y DropOutLengthInUngappedExtension]\n"
+            "             [-g OutputEnergyThreshold] [-s OutputStyle] [-a ParallelAlgorithm] [-p TemporaryPath]\n"
+            "\n"
+            "  Options:\n"
+            "(Required)\n"
+            "    -i STR    RNA sequences in FASTA format\n"
+            "    -d STR    Input database in pRIblast format\n"
+            "    -o STR    Output file name\n"
+            "\n"
+            "(Optional)\n"
+            "    -l INT    Max size of seed length [default:20]\n"
+            "    -e DBL    Hybridization energy threshold for seed search [default: -6.0]\n"
+            "    -f DBL    Interaction energy threshold for removal of the interaction candidate before gapped "
+            "extension [default: -4.0]\n"
+            "    -x INT    Dropout Length in gapped extension [default:16]\n"
+            "    -y INT    Dropout Length in ungapped extension [default:5]\n"
+            "    -g DBL    Energy threshold for output [default:-8.0]\n"
+            "    -s INT    Designation of output format style. 0:simplified output, or 1:detailed output [default:0]\n"
+            "    -m INT    Minimum helix length in gapped extension [default:3]\n"
+            "    -a STR    accepted for compatibility (block, area, dynamic); ignored\n"
+            "    -p STR    accepted for compatibility; ignored\n"
+            "\n"
+            "  Environment: PRB_DEVICES=0,1,..  GPUs to use;  PRB_BATCH=N  queries per batch [default 1024]");
+}
+
+struct Args {
+  std::string in, out, db;
+  prb_ris_opts o;
+};
+
+[[noreturn]] void die(const std::string &msg) {
+  std::fprintf(stderr, "%s\n", msg.c_str());
+  std::exit(1);
+}
+
+struct Worker {
+  int device;
+  prb_ctx *ctx = nullptr;
+  prb_db *db = nullptr;
+};
+
+// lines of one batch, without the Id column (SaveMyResults, rna_interaction_search.cpp:322-369)
+void run_batch(Worker &w, const Args &a, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
+               size_t b0, size_t b1, int W, int delta, int repeat_flag, int npages, std::string &lines) {
+  std::string cat;
+  std::vector<int64_t> off(b1 - b0 + 1, 0);
+  for (size_t i = b0; i < b1; i++) {
+    cat += seqs[i];
+    off[i - b0 + 1] = (int64_t)cat.size();
+  }
+  prb_qbatch *qb = nullptr;
+  if (prb_qbatch_create(w.ctx, (int32_t)(b1 - b0), cat.data(), off.data(), repeat_flag, &qb)) die(prb_last_error());
+  if (prb_qbatch_accessibility(w.ctx, qb, W, delta)) die(prb_last_error());
+  // per query, pages in order: collect per (query, page) so the text is grouped like the reference's
+  std::vector<std::string> per_q(b1 - b0);
+  char buf[512];
+  for (int page = 0; page < npages; page++) {
+    prb_hitset *hs = nullptr;
+    if (prb_search_page(w.ctx, qb, w.db, page, &a.o, 3, &hs)) die(prb_last_error());
+    const int64_t n = prb_hitset_size(hs);
+    const prb_hit *h = prb_hitset_hits(hs);
+    int64_t nbp = 0;
+    const int32_t *bp = prb_hitset_basepairs(hs, &nbp);
+    for (int64_t i = 0; i < n; i++) {
+      const prb_hit &x = h[i];
+      int32_t len = 0, len_rep = 0, sp = 0;
+      prb_db_seq_lengths(w.db, page, x.db_id, &len, &len_rep, &sp);
+      std::string &s = per_q[x.query];
+      std::snprintf(buf, sizeof buf, ",%d,", prb_qbatch_length_unmasked(qb, x.query));
+      s += names[b0 + x.query];
+      s += buf;
+      s += prb_db_seq_name(w.db, page, x.db_id);
+      std::snprintf(buf, sizeof buf, ",%d,%g,%g,%g,", len_rep, x.e_acc, x.e_hyb, x.e_tot);
+      s += buf;
+      const int32_t *p = bp + 2 * x.bp_offset;
+      auto fwd = [&](int32_t dbpos) { return (len - 1) - (dbpos - sp); }; // reversed text -> forward coordinate
+      if (a.o.output_style == 1) {
+        for (int32_t j = 0; j < x.bp_count; j++) {
+          std::snprintf(buf, sizeof buf, "(%d:%d) ", p[2 * j], fwd(p[2 * j + 1]));
+          s += buf;
+        }
+      } else if (x.bp_count > 0) {
+        const int32_t l = x.bp_count - 1;
+        std::snprintf(buf, sizeof buf, "(%d-%d:%d-%d) ", p[0], p[2 * l], fwd(p[1]), fwd(p[2 * l + 1]));
+        s += buf;
+      }
+      s += "\n";
+    }
+    prb_hitset_free(hs);
+  }
+  prb_qbatch_destroy(qb);
+  for (auto &s : per_q) lines += s;
+}
+
+int ris_main(int argc, char **argv) {
+  Args a;
+  prb_ris_opts_default(&a.o);
+  int c;
+  while ((c = getopt(argc, argv, "i:o:d:l:e:y:x:f:g:s:m:p:a:")) != -1) {
+    switch (c) {
+    case 'i': a.in = optarg; break;
+    case 'o': a.out = optarg; break;
+    case 'd': a.db = optarg; break;
+    case 'l': a.o.max_seed_length = std::atoi(optarg); break;
+    case 'e': a.o.hybrid_threshold = std::atof(optarg); break;
+    case 'f': a.o.interaction_threshold = std::atof(optarg); break;
+    case 'g': a.o.final_threshold = std::atof(optarg); break;
+    case 's': a.o.output_style = std::atoi(optarg); break;
+    case 'x': a.o.drop_out_w_gap = std::atoi(optarg); break;
+    case 'y': a.o.drop_out_wo_gap = std::atoi(optarg); break;
+    case 'm': a.o.min_helix_length = std::atoi(optarg); break;
+    case 'p': break;
+    case 'a':
+      if (std::strcmp(optarg, "block") && std::strcmp(optarg, "area") && std::strcmp(optarg, "dynamic"))
+        die("Error: parallel algorithm not supported.");
+      break;
+    default: die("Error: invalid argument");
+    }
+  }
+  std::vector<std::string> names, seqs;
+  std::string err = prb::read_fasta(a.in, names, seqs);
+  if (!err.empty()) die(err);
+
+  std::vector<int> devices;
+  if (const char *env = std::getenv("PRB_DEVICES")) {
+    for (const char *p = env; *p;) {
+      devices.push_back(std::atoi(p));
+      while (*p && *p != ',') p++;
+      if (*p == ',') p++;
+    }
+  }
+  if (devices.empty()) devices.push_back(0);
+  std::vector<Worker> workers(devices.size());
+  int hash_size = 0, repeat_flag = 0, W = 0, delta = 0, npages = 0;
+  for (size_t k = 0; k < devices.size(); k++) {
+    workers[k].device = devices[k];
+    if (prb_ctx_create(devices[k], nullptr, &workers[k].ctx)) die(std::string("Error: ") + prb_last_error());
+    if (prb_db_open(workers[k].ctx, a.db.c_str(), &workers[k].db)) die(prb_last_error());
+  }
+  prb_db_info(workers[0].db, &hash_size, &repeat_flag, &W, &delta, &npages);
+
+  std::FILE *out = std::fopen(a.out.c_str(), "w");
+  if (!out) die("Error: can't open output_file: " + a.out);
+  // MergeOutput header, rna_interaction_search.cpp:445-463
+  std::fprintf(out, "RIblast ris result\n");
+  std::fprintf(out,
+               "input:%s,database:%s,RepeatFlag:%d,MaximalSpan:%d,MinAccessibleLength:%d,MaxSeedLength:%d,"
+               "InteractionEnergyThreshold:%g,HybridEnergyThreshold:%g,FinalThreshold:%g,DropOutLengthWoGap:%d,"
+               "DropOutLengthWGap:%d\n",
+               a.in.c_str(), a.db.c_str(), repeat_flag, W, delta, a.o.max_seed_length, a.o.interaction_threshold,
+               a.o.hybrid_threshold, a.o.final_threshold, a.o.drop_out_wo_gap, a.o.drop_out_w_gap);
+  std::fprintf(out, "Id,Query name, Query Length, Target name, Target Length, Accessibility Energy, Hybridization Energy, "
+                    "Interaction Energy, BasePair\n");
+
+  const char *benv = std::getenv("PRB_BATCH");
+  const size_t batch = std::max(1, benv ? std::atoi(benv) : 1024);
+  const size_t nb = (seqs.size() + batch - 1) / batch;
+  std::vector<std::string> results(nb);
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> threads;
+  for (auto &w : workers)
+    threads.emplace_back([&, pw = &w] {
+      for (;;) {
+        const size_t b = next.fetch_add(1);
+        if (b >= nb) break;
+        run_batch(*pw, a, names, seqs, b * batch, std::min(seqs.size(), (b + 1) * batch), W, delta, repeat_flag, npages,
+                  results[b]);
+      }
+    });
+  for (auto &t : threads) t.join();
+  long id = 0;
+  for (auto &r : results) {
+    const char *p = r.data(), *end = p + r.size();
+    while (p < end) {
+      const char *nl = static_cast<const char *>(std::memchr(p, '\n', end - p));
+      std::fprintf(out, "%ld,", id++);
+      std::fwrite(p, 1, nl - p + 1, out);
+      p = nl + 1;
+    }
+  }
+  std::fclose(out);
+  for (auto &w : workers) {
+    prb_db_close(w.db);
+    prb_ctx_destroy(w.ctx);
+  }
+  return 0;
+}
+
+// `db` sub-command (db_construction_parameters.cpp getopt string "i:o:r:s:w:d:c:a:p:",
+// defaults db_construction_parameters.hpp:41-52): same files as the reference writes.
+int db_main(int argc, char **argv) {
+  std::string in, out;
+  int repeat = 0, hash = 8, W = 70, delta = 5, chunk = 2147483647;
+  int c;
+  while ((c = getopt(argc, argv, "i:o:r:s:w:d:c:a:p:")) != -1) {
+    switch (c) {
+    case 'i': in = optarg; break;
+    case 'o': out = optarg; break;
+    case 'r': repeat = std::atoi(optarg); break;
+    case 's': hash = std::atoi(optarg); break;
+    case 'w': W = std::atoi(optarg); break;
+    case 'd': delta = std::atoi(optarg); break;
+    case 'c': chunk = std::atoi(optarg); break;
+    case 'a': case 'p': break;
+    default: die("Error: invalid argument");
+    }
+  }
+  if (out.empty()) die("Error: -o option is required");
+  if (delta <= 1) die("Error: -d option must be greater than 1");
+  if (repeat < 0 || repeat > 2) die("Error: -r option must be 0, 1, or 2");
+  std::vector<std::string> names, seqs;
+  std::string err = prb::read_fasta(in, names, seqs);
+  if (!err.empty()) die(err);
+  std::string cat;
+  std::vector<int64_t> off(seqs.size() + 1, 0);
+  std::vector<const char *> np;
+  for (size_t i = 0; i < seqs.size(); i++) {
+    cat += seqs[i];
+    off[i + 1] = (int64_t)cat.size();
+    np.push_back(names[i].c_str());
+  }
+  prb_ctx *ctx = nullptr;
+  const char *env = std::getenv("PRB_DEVICES");
+  if (prb_ctx_create(env ? std::atoi(env) : 0, nullptr, &ctx)) die(std::string("Error: ") + prb_last_error());
+  if (prb_db_build(ctx, out.c_str(), (int32_t)seqs.size(), np.data(), cat.data(), off.data(), repeat, hash, W, delta, chunk))
+    die(std::string("Error: ") + prb_last_error());
+  prb_ctx_destroy(ctx);
+  return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+  if (argc == 1 || std::strcmp(argv[1], "-h") == 0) {
+    usage();
+    return 0;
+  }
+  if (std::strcmp(argv[1], "ris") == 0) return ris_main(argc - 1, argv + 1);
+  if (std::strcmp(argv[1], "db") == 0) return db_main(argc - 1, argv + 1);
+  std::puts("usage: pRIblast-hip [-h] {db | ris} options");
+  return 0;
+}
