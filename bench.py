@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
-STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "traceback")
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_slow", "traceback", "traceback_slow")
 
 
 def parse():
@@ -206,6 +206,7 @@ def main():
                        "hits_per_step": {"seed": allc[0] // a.steps, "ungapped": allc[1] // a.steps, "final": allc[2] // a.steps},
                        "parallelism": f"queries sharded over {world} GPU(s), final hits gathered over RCCL"},
             "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
+            "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
             "roofline": {"bound": "hbm", "kernel": "k_gapped", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": gap_launch, "avg_launch_ms": gap_ms / max(gap_launch, 1),

@@ -178,13 +178,21 @@ int prb_ctx_synchronize(prb_ctx *ctx) {
 
 int prb_ctx_stage_ms(prb_ctx *ctx, const char *stage, double *ms, int64_t *launches) {
   if (!ctx || !stage) return PRB_ERR_ARG;
+  if (std::strcmp(stage, "slow_hits") == 0) { // counter, not a timer
+    if (ms) *ms = 0;
+    if (launches) *launches = ctx->slow_hits;
+    return PRB_OK;
+  }
   auto it = ctx->timers.find(stage);
   if (ms) *ms = it == ctx->timers.end() ? 0.0 : it->second.ms;
   if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.launches;
   return PRB_OK;
 }
 void prb_ctx_reset_timers(prb_ctx *ctx) {
-  if (ctx) ctx->timers.clear();
+  if (ctx) {
+    ctx->timers.clear();
+    ctx->slow_hits = 0;
+  }
 }
 
 } // extern "C"

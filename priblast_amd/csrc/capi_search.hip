@@ -35,11 +35,12 @@ struct PageMem {
 // buffers reused across prb_search_page calls
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
-      state, keep, pending, surv, count, first, gapScratch, overflow, subset, bpCount, bpOff, bpOut, scanTmp;
+      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, bpCount, bpOff, bpOut, bpCount2, bpOff2,
+      scanTmp;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &bpCount, &bpOff, &bpOut, &scanTmp})
+                      &subset, &subset2, &bpCount, &bpOff, &bpOut, &bpCount2, &bpOff2, &scanTmp})
       b->release();
   }
 };
@@ -92,6 +93,7 @@ struct prb_hitset {
   std::vector<prb_hit> hits;
   std::vector<int32_t> bp;
   int64_t counts[3] = {0, 0, 0};
+  int64_t slow_hits = 0; // extensions that outgrew the LDS kernel
 };
 
 namespace prb {
@@ -646,61 +648,82 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = w.hitsC.ensure(hits_bytes(nung)))) return rc;
   HitSoA G = carve_hits(w.hitsC, nung);
   if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4))) return rc;
+  int64_t hs_slow = 0;
+  const bool force_wave = getenv("PRB_FORCE_WAVE_GAPPED") != nullptr; // testing: bypass the LDS kernel
   auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
-    const int64_t maxthreads = 256 * 768;
-    int64_t nt = std::min<int64_t>(((n + 255) / 256) * 256, maxthreads);
     gs.cap_diag = cap_diag;
     gs.cap_rec = cap_rec;
-    gs.bytes_per_thread = (size_t)cap_diag * 16 + (size_t)cap_rec * 16;
-    while (nt > 256 && (size_t)nt * gs.bytes_per_thread > ((size_t)6 << 30)) nt = ((nt / 2 + 255) / 256) * 256;
-    gs.nthreads = (int32_t)nt;
-    int r = w.gapScratch.ensure((size_t)nt * gs.bytes_per_thread);
+    gs.bytes_per_thread = gapped_wave_scratch_bytes(cap_diag, cap_rec);
+    int64_t nw = std::min<int64_t>(n, 4096);
+    while (nw > 64 && (size_t)nw * gs.bytes_per_thread > ((size_t)4 << 30)) nw /= 2;
+    gs.nthreads = (int32_t)nw;
+    int r = w.gapScratch.ensure((size_t)nw * gs.bytes_per_thread);
     gs.base = w.gapScratch.as<uint8_t>();
     return r;
   };
-  // runs `mode` over the hit list `subset` (or all n), growing the scratch for hits that overflow
-  // extends every hit of U into G, growing the scratch for the hits that overflow it
-  auto run_gapped = [&](int64_t n) -> int {
-    const uint32_t *subset = nullptr;
-    int cap_diag = 128, cap_rec = 320;
-    GapScratch gs;
-    if ((rc = scratch_for(n, cap_diag, cap_rec, gs))) return rc;
-    PRB_HIP(launch_gapped(U, G, n, subset, qb->view, pd, sc, eo, gs, 0, w.overflow.as<uint8_t>(), w.first.as<uint8_t>(),
-                          nullptr, nullptr, nullptr, ctx->stream));
-    // collect overflowed hits and retry with 4x the scratch until none is left
-    std::vector<uint8_t> ov((size_t)n);
-    std::vector<uint32_t> sub;
-    const uint32_t *cur = subset;
-    std::vector<uint32_t> cur_host;
-    int64_t cur_n = n;
-    for (;;) {
-      PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)cur_n, hipMemcpyDeviceToHost, ctx->stream));
+  // Slow path: wave-per-hit kernel with its state in HBM scratch, for the hit list `list`
+  // (indices into U), growing the scratch 4x for hits that still overflow.  mode 0 writes G; modes 1/2 use
+  // cnt_dev / off_dev (indexed by position in `list`).
+  auto run_slow = [&](int mode, std::vector<uint32_t> list, int32_t *cnt_dev, const int64_t *off_dev) -> int {
+    int cap_diag = 512, cap_rec = 2048;
+    if (mode != 0) { // caps known to suffice for every hit seen so far
+      cap_diag = std::max(512, ctx->max_gap_caps);
+      cap_rec = cap_diag * 4;
+    }
+    std::vector<uint8_t> ov;
+    while (!list.empty()) {
+      GapScratch gs;
+      const int64_t m = (int64_t)list.size();
+      if ((rc = scratch_for(m, cap_diag, cap_rec, gs))) return rc;
+      if ((rc = w.subset2.ensure((size_t)m * 4))) return rc;
+      PRB_HIP(hipMemcpyAsync(w.subset2.p, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+      PRB_HIP(launch_gapped_wave(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, gs, mode,
+                            mode == 0 ? w.overflow.as<uint8_t>() : nullptr, w.first.as<uint8_t>(), cnt_dev, off_dev,
+                            w.bpOut.as<int32_t>(), ctx->stream));
+      ctx->timers["gapped_slow"].launches++;
+      if (mode != 0) break;
+      ov.resize((size_t)m);
+      PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
       PRB_HIP(hipStreamSynchronize(ctx->stream));
-      sub.clear();
-      for (int64_t i = 0; i < cur_n; i++)
-        if (ov[i]) sub.push_back(cur ? cur_host[i] : (uint32_t)i);
-      if (sub.empty()) break;
+      std::vector<uint32_t> again;
+      for (int64_t i = 0; i < m; i++)
+        if (ov[i]) again.push_back(list[i]);
+      list.swap(again);
+      if (list.empty()) break;
       cap_diag *= 4;
       cap_rec *= 4;
       if (cap_diag > 32768) {
         set_error("gapped extension exceeds the supported extension length (32768)");
         return PRB_ERR_STATE;
       }
-      if (cap_rec > 65535) cap_rec = 65535;
       ctx->max_gap_caps = std::max(ctx->max_gap_caps, cap_diag);
-      cur_host = sub;
-      cur_n = (int64_t)sub.size();
-      PRB_HIP(hipMemcpyAsync(w.subset.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-      cur = w.subset.as<uint32_t>();
-      if ((rc = scratch_for(cur_n, cap_diag, cap_rec, gs))) return rc;
-      PRB_HIP(launch_gapped(U, G, cur_n, cur, qb->view, pd, sc, eo, gs, 0, w.overflow.as<uint8_t>(), w.first.as<uint8_t>(),
-                            nullptr, nullptr, nullptr, ctx->stream));
     }
     return PRB_OK;
   };
-  if ((rc = ctx->time_begin())) return rc;
+  // extends every hit of U into G: cooperative LDS kernel first, slow path for its overflows
+  auto run_gapped = [&](int64_t n) -> int {
+    std::vector<uint8_t> ov((size_t)n, 1);
+    if (!force_wave) {
+    if ((rc = ctx->time_begin())) return rc;
+    PRB_HIP(launch_gapped_lds(U, G, n, nullptr, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.first.as<uint8_t>(),
+                              nullptr, nullptr, nullptr, ctx->stream));
+    if ((rc = ctx->time_end("gapped", 1))) return rc;
+    PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint32_t> list;
+    for (int64_t i = 0; i < n; i++)
+      if (ov[i]) list.push_back((uint32_t)i);
+    hs_slow += (int64_t)list.size();
+    if (list.empty()) return PRB_OK;
+    if ((rc = ctx->time_begin())) return rc;
+    if ((rc = run_slow(0, std::move(list), nullptr, nullptr))) return rc;
+    return ctx->time_end("gapped_slow", 0);
+  };
   if ((rc = run_gapped(nung))) return rc;
-  if ((rc = ctx->time_end("gapped", 1))) return rc;
+  hs->slow_hits += hs_slow;
+  ctx->timers["gapped_slow"].launches += 0;
+  ctx->slow_hits += hs_slow;
 
   // ---- final sort + filter ----
   HitSoA S = carve_hits(w.hitsB, nung);
@@ -723,17 +746,35 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // ---- traceback of the survivors: re-run their extension, count then write base pairs ----
   if ((rc = ctx->time_begin())) return rc;
   if ((rc = w.bpCount.ensure((size_t)(nfin + 1) * 4)) || (rc = w.bpOff.ensure((size_t)(nfin + 1) * 8))) return rc;
-  // scratch large enough for every hit of this list: the largest caps any hit needed so far
   {
-    int cap_diag = std::max(128, ctx->max_gap_caps), cap_rec = std::min(65535, cap_diag / 128 * 320);
-    GapScratch gs;
-    if ((rc = scratch_for(nfin, cap_diag, cap_rec, gs))) return rc;
-    PRB_HIP(hipMemsetAsync(w.bpCount.p, 0, (size_t)(nfin + 1) * 4, ctx->stream));
-    PRB_HIP(launch_gapped(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, gs, 1, nullptr, w.first.as<uint8_t>(),
-                          w.bpCount.as<int32_t>(), nullptr, nullptr, ctx->stream));
+    std::vector<uint32_t> pre((size_t)nfin); // index of each final hit's pre-gapped state in U
+    PRB_HIP(hipMemcpyAsync(pre.data(), w.subset.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipMemsetAsync(w.bpCount.p, force_wave ? 0xFF : 0, (size_t)(nfin + 1) * 4, ctx->stream));
+    if (!force_wave)
+      PRB_HIP(launch_gapped_lds(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, 1, nullptr, w.first.as<uint8_t>(),
+                                w.bpCount.as<int32_t>(), nullptr, nullptr, ctx->stream));
     std::vector<int32_t> cnt((size_t)nfin);
     PRB_HIP(hipMemcpyAsync(cnt.data(), w.bpCount.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
+    // hits beyond the LDS capacities: count (and later write) through the slow path
+    std::vector<uint32_t> slow_pos, slow_list;
+    for (int64_t i = 0; i < nfin; i++)
+      if (cnt[i] < 0) {
+        slow_pos.push_back((uint32_t)i);
+        slow_list.push_back(pre[i]);
+      }
+    if (!slow_list.empty()) {
+      if ((rc = w.bpCount2.ensure(slow_list.size() * 4)) || (rc = w.bpOff2.ensure(slow_list.size() * 8))) return rc;
+      if ((rc = ctx->time_end("traceback", 1))) return rc;
+      if ((rc = ctx->time_begin())) return rc;
+      if ((rc = run_slow(1, slow_list, w.bpCount2.as<int32_t>(), nullptr))) return rc;
+      if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
+      if ((rc = ctx->time_begin())) return rc;
+      std::vector<int32_t> c2(slow_list.size());
+      PRB_HIP(hipMemcpyAsync(c2.data(), w.bpCount2.p, c2.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t k = 0; k < c2.size(); k++) cnt[slow_pos[k]] = c2[k];
+    }
     std::vector<int64_t> off((size_t)nfin + 1, 0);
     for (int64_t i = 0; i < nfin; i++) {
       if (cnt[i] < 0) {
@@ -745,8 +786,19 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
     PRB_HIP(hipMemcpyAsync(w.bpOff.p, off.data(), (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    PRB_HIP(launch_gapped(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, gs, 2, nullptr, w.first.as<uint8_t>(),
-                          nullptr, w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
+    if (!force_wave)
+      PRB_HIP(launch_gapped_lds(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, 2, nullptr, w.first.as<uint8_t>(),
+                                nullptr, w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
+    if (!slow_list.empty()) {
+      std::vector<int64_t> o2(slow_list.size());
+      for (size_t k = 0; k < o2.size(); k++) o2[k] = off[slow_pos[k]];
+      PRB_HIP(hipMemcpyAsync(w.bpOff2.p, o2.data(), o2.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = ctx->time_end("traceback", 1))) return rc;
+      if ((rc = ctx->time_begin())) return rc;
+      if ((rc = run_slow(2, slow_list, nullptr, w.bpOff2.as<int64_t>()))) return rc;
+      if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
+      if ((rc = ctx->time_begin())) return rc;
+    }
     const size_t bp_base = hs->bp.size();
     hs->bp.resize(bp_base + (size_t)total * 2);
     if (total) PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpOut.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));

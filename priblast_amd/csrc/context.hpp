@@ -48,6 +48,7 @@ struct prb_ctx {
   // int tables for the search stages (search_kernels.hip)
   void *search_const = nullptr;
   void *search_ws = nullptr;   // prb::SearchWs, capi_search.hip
+  int64_t slow_hits = 0;       // extensions that went through the HBM-scratch fallback kernel
   int max_gap_caps = 128;      // largest diagonal capacity any gapped extension has needed
   prb::DevBuf d_expd, d_log, d_small, d_big;
   // Raccess workspaces

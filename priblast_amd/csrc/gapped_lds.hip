@@ -1,0 +1,484 @@
+// Gapped extension on gfx950 (GappedExtension::Run / extension / CheckHelixLength / traceback /
+// CalcDangleEnergy / LoopEnergy, gapped_extension.cpp:33-473).
+//
+// A GROUP of lanes owns one hit and keeps the whole DP state of one direction on chip:
+//   * the list of filled cells - which is also the stem-candidate list: cells are pushed in
+//     (anti-diagonal, i) order and pruned from the front (gapped_extension.cpp:213-217), so the
+//     live candidates are always a contiguous range [lo, start of this anti-diagonal);
+//   * the cumulative accessibility changes eq[], ed[] (gapped_extension.cpp:156-212);
+//   * Cell::type (= the PREDECESSOR's stem type, gapped_extension.cpp:256-258) by i for the last
+//     three anti-diagonals, for CheckHelixLength's (i-1, j-1) lookup.
+// Cells of an anti-diagonal are checked G at a time (one per lane); the candidates of a filled
+// cell are scanned G at a time and reduced with an order-preserving (energy, index) minimum,
+// i.e. "first candidate in list order wins under strict <"; the scalars of the recurrence are
+// kept redundantly in every lane.  The reference's growing 100x100 Cell matrix never exists.
+//
+// Two instantiations:
+//   k_gapped_lds   G = 16, state in LDS (3.3 KB per hit; 16 hits per workgroup): > 99.8 % of hits
+//   k_gapped_wave  G = 64, state in HBM scratch sized at run time: the rest (extensions longer
+//                  than 64 anti-diagonals or with more than 128 filled cells per direction)
+// Why: an extension is small (median 16 anti-diagonals, ~10 filled cells per direction) but its
+// cell list is re-read for every filled cell; per-thread scratch in HBM made every access a
+// dependent HBM round trip (r01 baseline profile: 117 ns/hit; LDS form: 19 ns/hit).
+#include <algorithm>
+
+#include "search_device.hpp"
+#include "search_kernels.hpp"
+
+namespace prb {
+
+namespace {
+
+constexpr int kCapD = 64;  // anti-diagonals per direction held in LDS
+constexpr int kCapR = 128; // filled cells per direction held in LDS
+constexpr int kLdsGroup = 16;
+constexpr int kLdsGroupsPerBlock = 16;
+
+// filled cell r: i | j << 16 | type << 32 | ptype << 36 | pred << 40
+__device__ __forceinline__ uint64_t pack(int i, int j, int pred, int type, int ptype) {
+  return (uint64_t)(uint32_t)i | ((uint64_t)(uint32_t)j << 16) | ((uint64_t)type << 32) | ((uint64_t)ptype << 36) |
+         ((uint64_t)(uint32_t)pred << 40);
+}
+__device__ __forceinline__ int rec_i(uint64_t v) { return (int)(v & 0xFFFF); }
+__device__ __forceinline__ int rec_j(uint64_t v) { return (int)((v >> 16) & 0xFFFF); }
+__device__ __forceinline__ int rec_type(uint64_t v) { return (int)((v >> 32) & 0xF); }
+__device__ __forceinline__ int rec_pred(uint64_t v) { return (int)(v >> 40); }
+
+struct LdsState {
+  double eq[kCapD], ed[kCapD];
+  double hyb[kCapR];
+  uint64_t info[kCapR];
+  uint8_t ptab[3][kCapD + 16];
+};
+struct LdsStore {
+  LdsState &s;
+  __device__ __forceinline__ int cap_d() const { return kCapD; }
+  __device__ __forceinline__ int cap_r() const { return kCapR; }
+  __device__ __forceinline__ double &eq(int i) const { return s.eq[i]; }
+  __device__ __forceinline__ double &ed(int i) const { return s.ed[i]; }
+  __device__ __forceinline__ double &hyb(int r) const { return s.hyb[r]; }
+  __device__ __forceinline__ uint64_t &info(int r) const { return s.info[r]; }
+  __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return s.ptab[row][i]; }
+  __device__ __forceinline__ int ptab_len() const { return kCapD + 16; }
+};
+struct HbmStore { // one block of the scratch per group
+  double *eq_, *ed_, *hyb_;
+  uint64_t *info_;
+  uint8_t *ptab_;
+  int capd, capr;
+  __device__ __forceinline__ int cap_d() const { return capd; }
+  __device__ __forceinline__ int cap_r() const { return capr; }
+  __device__ __forceinline__ double &eq(int i) const { return eq_[i]; }
+  __device__ __forceinline__ double &ed(int i) const { return ed_[i]; }
+  __device__ __forceinline__ double &hyb(int r) const { return hyb_[r]; }
+  __device__ __forceinline__ uint64_t &info(int r) const { return info_[r]; }
+  __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return ptab_[(size_t)row * (capd + 16) + i]; }
+  __device__ __forceinline__ int ptab_len() const { return capd + 16; }
+};
+
+// State traffic inside a group is produced and consumed by lanes of ONE wavefront; its
+// memory instructions execute in order, so ordering only needs the compiler held back
+// (LDS) plus completion of the stores (HBM scratch: workgroup-scope fence).
+template <bool kLds> __device__ __forceinline__ void group_sync() {
+  if (kLds) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+struct DirResult {
+  bool overflow;
+  int best; // cell index of the arg-min, 0 = nothing found
+};
+
+// GappedExtension::extension (gapped_extension.cpp:71-319) for one direction, by a group of G lanes.
+template <int G, bool kLds, class Store>
+__device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, HitState &h, int flag, const uint8_t *qs,
+                                      const float *qacc, const float *qcond, const uint8_t *ds, const float *dacc,
+                                      const float *dcond, const Store &S, int gl /* lane in group */, int gbase /* first lane of the group in its wavefront */) {
+  const int MAXE = 100000;
+  const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
+  double min_e = h.e_tot;
+  const double first_a = h.e_acc;
+  double min_a = first_a;
+  int q_start;
+  int64_t db_start;
+  if (flag == 0) {
+    q_start = h.q_sp;
+    db_start = h.db_sp;
+  } else {
+    q_start = h.q_sp + h.q_len - 1;
+    db_start = (int64_t)h.db_sp + h.db_len - 1;
+  }
+  int max_q = MAXE, max_d = MAXE;
+  const int id_start = h.id_start, id_end = id_start + h.db_len - 1;
+  int min_q_start = q_start;
+  int64_t min_db_start = db_start;
+  const int q_length = h.q_len, db_length = h.db_len;
+  int min_q_len = q_length, min_db_len = db_length, min_id_start = id_start;
+  int length = 0, min_length = 0, best = 0;
+  bool overflow = false;
+
+  int type0 = bp_type(sc, get_char(qs, q_start), get_char(ds, db_start));
+  if (flag == 0) type0 = sc.rtype[type0];
+  for (int t = gl; t < 3 * S.ptab_len(); t += G) S.ptab(0, t) = 0;
+  group_sync<kLds>();
+  if (gl == 0) {
+    S.hyb(0) = min_e;
+    S.info(0) = pack(0, 0, 0, type0, type0);
+    S.ptab(0, 0) = (uint8_t)type0; // cell (0,0) lies on anti-diagonal 0
+  }
+  group_sync<kLds>();
+  int nrec = 1, lo = 0;
+  double eq_prev = 0, ed_prev = 0;
+
+  for (;;) {
+    length++;
+    if (length > S.cap_d()) {
+      overflow = true;
+      break;
+    }
+    if (flag == 0) {
+      if (max_q == MAXE && (q_start - length < 0 || qs[q_start - length] < 2)) max_q = length - 1;
+      if (max_d == MAXE && (db_start - length < 0 || ds[db_start - length] < 2)) max_d = length - 1;
+    } else {
+      if (max_q == MAXE && qs[q_start + length] < 2) max_q = length - 1;
+      if (max_d == MAXE && ds[db_start + length] < 2) max_d = length - 1;
+    }
+    // cumulative accessibility change of the extension (:156-212), same value in every lane
+    if (max_q == MAXE) {
+      double v;
+      if (flag == 0) {
+        const int t = q_start - length;
+        if (length == 1) v = qacc[t] - qacc[t + 1] + qcond[t + delta];
+        else v = eq_prev + qacc[t] - qacc[t + 1] + qcond[t + delta];
+      } else {
+        if (length == 1) v = qcond[q_start + length];
+        else v = eq_prev + qcond[q_start + length];
+      }
+      eq_prev = v;
+      if (gl == 0) S.eq(length - 1) = v;
+    }
+    if (max_d == MAXE) {
+      double v;
+      if (flag == 0) {
+        if (length == 1) v = dcond[id_end + length];
+        else v = ed_prev + dcond[id_end + length];
+      } else {
+        const int t = id_start - length;
+        if (length == 1) v = dacc[t] - dacc[t + 1] + dcond[t + delta];
+        else v = ed_prev + dacc[t] - dacc[t + 1] + dcond[t + delta];
+      }
+      ed_prev = v;
+      if (gl == 0) S.ed(length - 1) = v;
+    }
+    const int cur = length % 3, d2 = (length + 1) % 3; // d2 = (length - 2) mod 3
+    // recycle the row of anti-diagonal length-3 for this one
+    for (int t = gl; t <= length; t += G) S.ptab(cur, t) = 0;
+    group_sync<kLds>();
+    // prune candidates with length - first - second - 2 > drop (:213-217): a prefix of the list
+    if (length - 2 > drop) {
+      while (lo < nrec) {
+        const uint64_t v = S.info(lo);
+        if (length - rec_i(v) - rec_j(v) - 2 > drop) lo++;
+        else break;
+      }
+    }
+    const int dstart = nrec;
+    const int i_lo = length - max_d > 1 ? length - max_d : 1;
+    const int i_hi = max_q < length - 1 ? max_q : length - 1;
+    for (int i0 = i_lo; i0 <= i_hi && !overflow; i0 += G) {
+      const int i = i0 + gl, j = length - i;
+      int type1 = 0;
+      if (i <= i_hi) {
+        // CheckHelixLength (:342-364)
+        type1 = ext_bp_type(sc, flag, qs, ds, q_start, db_start, i, j, 0);
+        if (type1 != 0) {
+          const int pt = S.ptab(d2, i - 1);
+          if (pt == 0 || (wobble(type1) && wobble(pt))) {
+            for (int x = 1; x <= min_helix - 1; x++) {
+              const int t = ext_bp_type(sc, flag, qs, ds, q_start, db_start, i, j, x);
+              if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
+                type1 = 0;
+                break;
+              }
+            }
+          }
+        }
+      }
+      unsigned long long vmask = __ballot(type1 != 0);
+      if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
+      while (vmask) { // filled cells of this chunk, ascending i
+        const int b = __builtin_ctzll(vmask);
+        vmask &= vmask - 1;
+        const int ci = i0 + b, cj = length - ci;
+        const int ctype = __shfl(type1, gbase + b);
+        // scan the live candidates [lo, dstart), G per round; strict '<' keeps the first
+        double bte = 1000000.0; // INF
+        int bk = lo;
+        for (int k0 = lo; k0 < dstart; k0 += G) {
+          const int k = k0 + gl;
+          if (k < dstart) {
+            const uint64_t v = S.info(k);
+            const int ri = rec_i(v), rj = rec_j(v);
+            if (ri < ci && rj < cj) {
+              double te;
+              if (flag == 0)
+                te = loop_energy_gapped(sc, ctype, rec_type(v), q_start - ci, (int)(db_start - cj), q_start - ri,
+                                        (int)(db_start - rj), qs, ds);
+              else
+                te = loop_energy_gapped(sc, rec_type(v), ctype, q_start + ri, (int)(db_start + rj), q_start + ci,
+                                        (int)(db_start + cj), qs, ds);
+              te += S.hyb(k);
+              if (te < bte) {
+                bte = te;
+                bk = k;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) { // (energy, index) minimum over the group
+          const double ote = __shfl_xor(bte, m);
+          const int ok = __shfl_xor(bk, m);
+          if (ote < bte || (ote == bte && ok < bk)) {
+            bte = ote;
+            bk = ok;
+          }
+        }
+        if (nrec >= S.cap_r()) {
+          overflow = true;
+          break;
+        }
+        if (lo >= dstart) bk = 0; // empty window: the reference reads stem_candidate[0] of an empty list
+        const int ptype = rec_type(S.info(bk));
+        if (gl == 0) {
+          S.hyb(nrec) = bte;
+          S.info(nrec) = pack(ci, cj, bk, sc.rtype[ctype], ptype);
+          S.ptab(cur, ci) = (uint8_t)ptype;
+        }
+        const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;
+        if (ie < min_e) {
+          min_e = ie;
+          min_a = first_a + S.eq(ci - 1) + S.ed(cj - 1);
+          min_length = length;
+          best = nrec;
+          if (flag == 0) {
+            min_q_start = q_start - ci;
+            min_db_start = db_start - cj;
+          } else {
+            min_id_start = id_start - cj;
+          }
+          min_q_len = q_length + ci;
+          min_db_len = db_length + cj;
+        }
+        nrec++;
+      }
+      group_sync<kLds>();
+    }
+    if (overflow) break;
+    if (length - min_length >= drop) break;
+    if (max_q != MAXE && max_d != MAXE) break;
+  }
+  DirResult r;
+  r.overflow = overflow;
+  r.best = (q_length - min_q_len != 0 && db_length - min_db_len != 0) ? best : 0;
+  h.id_start = min_id_start;
+  if (flag == 0) {
+    h.q_sp = min_q_start;
+    h.db_sp = (int)min_db_start;
+  }
+  h.q_len = min_q_len;
+  h.db_len = min_db_len;
+  h.e_tot = min_e;
+  h.e_acc = min_a;
+  h.e_hyb = min_e - min_a;
+  return r;
+}
+
+struct GapArgs {
+  HitSoA in, out;
+  int64_t n;
+  const uint32_t *subset;
+  QBatchDev qb;
+  PageDev pg;
+  SearchConst sc;
+  ExtOpts o;
+  uint8_t *overflow;
+  const uint8_t *first_flag;
+  int32_t *bp_count;
+  const int64_t *bp_off;
+  int32_t *bp_out;
+};
+
+// One hit (index w of the work list) by one group.  kMode 0: extend, write the hit to out;
+// 1: count the base pairs of the final alignment; 2: write them at bp_off[w].
+template <int kMode, int G, bool kLds, class Store>
+__device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, int gbase) {
+  const SearchConst &sc = a.sc;
+  const int64_t x = a.subset ? (int64_t)a.subset[w] : w;
+  const int query = a.in.query[x];
+  const int64_t qo = a.qb.off[query];
+  const uint8_t *qs = a.qb.enc + qo;
+  const int qn = a.qb.len[query] + 1;
+  const float *qacc = a.qb.acc + qo, *qcond = a.qb.cond + qo;
+  const uint8_t *ds = a.pg.seqs;
+  const int id = a.in.db_id[x];
+  const int64_t base = (int64_t)a.pg.start_pos[id] - id;
+  const float *dacc = a.pg.acc + base, *dcond = a.pg.cond + base;
+  HitState h;
+  h.q_sp = a.in.q_sp[x];
+  h.db_sp = a.in.db_sp[x];
+  h.q_len = a.in.q_len[x];
+  h.db_len = a.in.db_len[x];
+  h.id_start = a.in.db_id_start[x];
+  h.e_tot = a.in.e_tot[x];
+  h.e_acc = a.in.e_acc[x];
+  h.e_hyb = a.in.e_hyb[x];
+  const int diag_q = h.q_sp, diag_d = h.db_sp, diag_len = US(h.q_len); // the ungapped region
+
+  int ndiag = 0;
+  if (kMode != 0) // GetBasePair, rna_interaction_search.cpp:371-385 (every lane counts; cheap)
+    for (int t = 0; t < diag_len; t++) ndiag += sc.bp_pair[(qs[diag_q + t] - 1) * 5 + (ds[diag_d + t] - 1)] != 0;
+  const bool unsorted = kMode != 0 && a.first_flag && a.first_flag[x]; // hit 0 keeps raw pair order (:314-317)
+  const int64_t out0 = kMode == 2 ? a.bp_off[w] : 0;
+
+  bool ovf = false;
+  int nleft = 0, nright = 0;
+  for (int flag = 0; flag < 2 && !ovf; flag++) {
+    const int q_start = flag == 0 ? h.q_sp : h.q_sp + h.q_len - 1;
+    const int64_t db_start = flag == 0 ? (int64_t)h.db_sp : (int64_t)h.db_sp + h.db_len - 1;
+    const DirResult r = extend_dir_group<G, kLds>(sc, a.o, h, flag, qs, qacc, qcond, ds, dacc, dcond, S, gl, gbase);
+    ovf = r.overflow;
+    if (kMode != 0 && !ovf) {
+      // traceback (:300-308, :409-424): from the arg-min cell through the predecessors
+      int cnt = 0;
+      for (int k = r.best; k != 0; k = rec_pred(S.info(k))) cnt++;
+      if (flag == 0) nleft = cnt;
+      else nright = cnt;
+      if (kMode == 2 && gl == 0) {
+        int t = 0;
+        for (int k = r.best; k != 0; k = rec_pred(S.info(k)), t++) {
+          const uint64_t v = S.info(k);
+          int64_t pos;
+          int qv, dv;
+          if (flag == 0) { // emitted outermost first = ascending positions
+            qv = q_start - rec_i(v);
+            dv = (int)(db_start - rec_j(v));
+            pos = unsorted ? out0 + ndiag + t : out0 + t;
+          } else { // emitted outermost first = descending positions
+            qv = q_start + rec_i(v);
+            dv = (int)(db_start + rec_j(v));
+            pos = unsorted ? out0 + ndiag + nleft + t : out0 + nleft + ndiag + (cnt - 1 - t);
+          }
+          a.bp_out[2 * pos] = qv;
+          a.bp_out[2 * pos + 1] = dv;
+        }
+      }
+    }
+    group_sync<kLds>();
+  }
+  if (gl != 0) return;
+  if (kMode == 0) {
+    a.overflow[w] = ovf ? 1 : 0;
+    if (!ovf) {
+      // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
+      const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, qn, ds, a.pg.nchars);
+      const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, qs, qn,
+                                             ds, a.pg.nchars);
+      double e = h.e_tot, hy = h.e_hyb;
+      e += d0;
+      e += d1;
+      hy += d0;
+      hy += d1;
+      a.out.q_sp[x] = h.q_sp;
+      a.out.db_sp[x] = h.db_sp;
+      a.out.q_len[x] = h.q_len;
+      a.out.db_len[x] = h.db_len;
+      a.out.db_id[x] = id;
+      a.out.db_id_start[x] = h.id_start;
+      a.out.query[x] = query;
+      a.out.e_acc[x] = h.e_acc;
+      a.out.e_hyb[x] = hy;
+      a.out.e_tot[x] = e;
+    }
+  } else if (kMode == 1) {
+    a.bp_count[w] = ovf ? -1 : ndiag + nleft + nright;
+  } else if (!ovf) {
+    int t = 0;
+    const int64_t d0 = unsorted ? out0 : out0 + nleft;
+    for (int u = 0; u < diag_len; u++)
+      if (sc.bp_pair[(qs[diag_q + u] - 1) * 5 + (ds[diag_d + u] - 1)] != 0) {
+        a.bp_out[2 * (d0 + t)] = diag_q + u;
+        a.bp_out[2 * (d0 + t) + 1] = diag_d + u;
+        t++;
+      }
+  }
+}
+
+template <int kMode> __global__ __launch_bounds__(kLdsGroup *kLdsGroupsPerBlock) void k_gapped_lds(GapArgs a) {
+  __shared__ LdsState lds[kLdsGroupsPerBlock];
+  const int gl = threadIdx.x & (kLdsGroup - 1);
+  const int gbase = (threadIdx.x & 63) & ~(kLdsGroup - 1);
+  const int gid = threadIdx.x / kLdsGroup;
+  const LdsStore S{lds[gid]};
+  const int64_t ngroups = (int64_t)gridDim.x * kLdsGroupsPerBlock;
+  for (int64_t w = (int64_t)blockIdx.x * kLdsGroupsPerBlock + gid; w < a.n; w += ngroups)
+    gapped_one<kMode, kLdsGroup, true>(a, w, S, gl, gbase);
+}
+
+template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs a, GapScratch scratch) {
+  const int gl = threadIdx.x;
+  uint8_t *mine = scratch.base + (size_t)blockIdx.x * scratch.bytes_per_thread; // one block of scratch per wavefront
+  HbmStore S;
+  S.capd = scratch.cap_diag;
+  S.capr = scratch.cap_rec;
+  S.eq_ = reinterpret_cast<double *>(mine);
+  S.ed_ = S.eq_ + S.capd;
+  S.hyb_ = S.ed_ + S.capd;
+  S.info_ = reinterpret_cast<uint64_t *>(S.hyb_ + S.capr);
+  S.ptab_ = reinterpret_cast<uint8_t *>(S.info_ + S.capr);
+  for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) gapped_one<kMode, 64, false>(a, w, S, gl, 0);
+}
+
+} // namespace
+
+size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
+  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 16);
+  return (b + 255) & ~(size_t)255;
+}
+
+hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
+                             const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, uint8_t *overflow,
+                             const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off, int32_t *bp_out,
+                             hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, first_flag, bp_count, bp_off, bp_out};
+  const int64_t want = (n + kLdsGroupsPerBlock - 1) / kLdsGroupsPerBlock;
+  const int blocks = (int)std::min<int64_t>(want, 256 * 3 * 8); // several rounds of resident workgroups
+  const dim3 blk(kLdsGroup * kLdsGroupsPerBlock);
+  if (mode == 0) hipLaunchKernelGGL(k_gapped_lds<0>, dim3(blocks), blk, 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(k_gapped_lds<1>, dim3(blocks), blk, 0, s, a);
+  else hipLaunchKernelGGL(k_gapped_lds<2>, dim3(blocks), blk, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
+                              const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
+                              uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
+                              int32_t *bp_out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, first_flag, bp_count, bp_off, bp_out};
+  const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
+  if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
+  else if (mode == 1) hipLaunchKernelGGL(k_gapped_wave<1>, dim3(blocks), dim3(64), 0, s, a, scratch);
+  else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);
+  return hipGetLastError();
+}
+
+} // namespace prb

@@ -88,17 +88,25 @@ hipError_t launch_filter_final(const HitSoA &h, int64_t n, const int64_t *pmax, 
                                hipStream_t s);
 // ---- gapped ----
 struct GapScratch {
-  uint8_t *base;        // per-thread blocks
-  size_t bytes_per_thread;
+  uint8_t *base;           // one block per wavefront
+  size_t bytes_per_thread; // bytes per block
   int32_t cap_rec, cap_diag;
-  int32_t nthreads;     // resident threads (grid * block)
+  int32_t nthreads;        // number of wavefronts (= grid size)
 };
-// mode 0: extend hits in place (coords + energies), overflow[i] = 1 if scratch was too small
-// mode 1: count base pairs of the final alignment into bp_count[i]
-// mode 2: write base pairs at bp_off[i]
-hipError_t launch_gapped(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
-                         const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
-                         uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
-                         int32_t *bp_out, hipStream_t s);
+size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
+// Gapped extension (gapped_lds.hip).  mode 0: extend hits (coords + energies) into `out`,
+// overflow[i] = 1 if the state capacity was too small; mode 1: count the base pairs of the final
+// alignment into bp_count[i] (-1 on overflow); mode 2: write them at bp_off[i].
+// launch_gapped_lds: 16 lanes per hit, state in LDS (fixed capacities).
+// launch_gapped_wave: one wavefront per hit, state in the HBM scratch (`scratch.nthreads`
+// wavefronts, `bytes_per_thread` bytes each = gapped_wave_scratch_bytes(cap_diag, cap_rec)).
+hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
+                             const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, uint8_t *overflow,
+                             const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off, int32_t *bp_out,
+                             hipStream_t s);
+hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
+                              const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
+                              uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
+                              int32_t *bp_out, hipStream_t s);
 
 } // namespace prb

@@ -112,3 +112,26 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
         for ext in ("bas", "seq", "acc", "nam", "ind"):
             with open(f"{out}.{ext}", "rb") as f, open(os.path.join(golden_dir, f"{tag}db.{ext}"), "rb") as g:
                 assert f.read() == g.read(), (tag, ext)
+
+
+def test_wave_fallback_kernel_matches_lds_kernel(ctx, golden_dir, monkeypatch):
+    """Every hit through the wave-per-hit / HBM-scratch kernel (normally only the extensions that
+    outgrow the LDS capacities) must give the same final hits and base pairs."""
+    from priblast_amd import capi
+    for tag in ("c1", "mix"):
+        names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
+        db = capi.Db(ctx, os.path.join(golden_dir, f"{tag}db"))
+        qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+        qb.accessibility(db.W, db.delta)
+        try:
+            for page in range(db.npages):
+                monkeypatch.delenv("PRB_FORCE_WAVE_GAPPED", raising=False)
+                h1, bp1, c1 = capi.search_page(ctx, qb, db, page)
+                monkeypatch.setenv("PRB_FORCE_WAVE_GAPPED", "1")
+                h2, bp2, c2 = capi.search_page(ctx, qb, db, page)
+                assert c1 == c2
+                assert np.array_equal(h1, h2) and np.array_equal(bp1, bp2)
+        finally:
+            monkeypatch.delenv("PRB_FORCE_WAVE_GAPPED", raising=False)
+            qb.close()
+            db.close()
