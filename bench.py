@@ -41,9 +41,9 @@ STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_slo
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--queries", type=int, default=int(os.environ.get("BENCH_QUERIES", 32)), help="queries per GPU per step")
+    ap.add_argument("--queries", type=int, default=int(os.environ.get("BENCH_QUERIES", 512)), help="queries per GPU per step")
     ap.add_argument("--db-seqs", type=int, default=int(os.environ.get("BENCH_DB_SEQS", 5000)))
     ap.add_argument("--length", type=int, default=int(os.environ.get("BENCH_LENGTH", 1000)))
     ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("BENCH_CPU_QUERIES", -1)),
@@ -62,14 +62,17 @@ def host_cores():
 def cpu_baseline(a, workdir, dbprefix, qnames, qseqs, log):
     """Reference `ris` (shipped flags, OpenMP over all host cores) on the first queries."""
     import gen_synthetic
-    cores = host_cores()
-    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.shipped")
-    # reference single-core cost: 0.43 ms/nt Raccess + 3.8 ns per (query nt x db nt) (BASELINE.md)
-    per_query = a.length * 0.43e-3 + 3.8e-9 * a.length * (a.db_seqs * (a.length + 1))
-    n = a.cpu_queries if a.cpu_queries >= 0 else max(cores, int(20.0 * cores / per_query))
-    n = max(1, min(n, len(qseqs)))
     if a.cpu_queries == 0:
         return None
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.shipped")
+    # Bounded sample: the reference needs ~20 s of one core per query at this database size
+    # (BASELINE.md: 0.43 ms/nt Raccess + 3.8 ns per query-nt x db-nt) and every OpenMP thread
+    # works on one whole query, so the sample is one query per thread on min(cores, 32) threads.
+    # (With all 256 threads of the GPU box busy the reference measured 0.66 queries/s, 263 queries
+    # in 401 s - worse per thread than at 32 threads; see profiles/README.md.)
+    cores = min(host_cores(), int(os.environ.get("BENCH_CPU_THREADS", 32)))
+    n = a.cpu_queries if a.cpu_queries > 0 else cores
+    n = max(1, min(n, len(qseqs)))
     sample = os.path.join(workdir, f"cpu_sample_{n}.fa")
     gen_synthetic.write_fasta(sample, zip(qnames[:n], qseqs[:n]))
     out = os.path.join(workdir, "cpu_sample.out")
@@ -90,7 +93,8 @@ def cpu_baseline(a, workdir, dbprefix, qnames, qseqs, log):
         nhits = max(0, sum(1 for _ in f) - 3)
     log(f"cpu baseline ({kind}): {n} queries in {dt:.1f} s on {cores} cores, {nhits} hits")
     return {"value": n / dt, "unit": "queries/s", "cores": cores, "kind": kind,
-            "sample": f"first {n} of the {len(qseqs)} queries vs the full database, {nhits} result lines, {dt:.1f} s wall"}
+            "sample": f"first {n} of the {len(qseqs)} queries (one per OpenMP thread) vs the full database, "
+                      f"{nhits} result lines, {dt:.1f} s wall"}
 
 
 def main():

@@ -23,7 +23,7 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
                       const int64_t *out_off, int W, int delta, float *d_acc, float *d_cond);
 
 struct SearchConstMem {
-  DevBuf ints, bulge;
+  DevBuf ints, bulge, div100;
   SearchConst view{};
 };
 
@@ -35,12 +35,12 @@ struct PageMem {
 // buffers reused across prb_search_page calls
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
-      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, bpCount, bpOff, bpOut, bpCount2, bpOff2,
+      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, ntrace, bpCount, bpOff, bpOut, bpCount2, bpOff2,
       scanTmp;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &bpCount, &bpOff, &bpOut, &bpCount2, &bpOff2, &scanTmp})
+                      &subset, &subset2, &ntrace, &bpCount, &bpOff, &bpOut, &bpCount2, &bpOff2, &scanTmp})
       b->release();
   }
 };
@@ -119,6 +119,19 @@ int prb_search_const_upload(prb_ctx *ctx) {
                o_11 = add(&p.int11_37[0][0][0][0], 1600), o_21 = add(&p.int21_37[0][0][0][0][0], 8000),
                o_22 = add(&p.int22_37[0][0][0][0][0][0], 40000), o_d5 = add(&p.dangle5_37[0][0], 40),
                o_d3 = add(&p.dangle3_37[0][0], 40);
+  {
+    using T = SearchTab;
+    if (o_stack != T::kStack || o_int != T::kInternal || o_mm != T::kMismatchI || o_11 != T::kInt11 || o_21 != T::kInt21 ||
+        o_22 != T::kInt22 || o_d5 != T::kDangle5 || o_d3 != T::kDangle3) {
+      set_error("internal error: SearchTab layout");
+      return PRB_ERR_STATE;
+    }
+    add(p.bulge37, 31);
+    int tau[8] = {0, 0, 0, p.terminal_au, p.terminal_au, p.terminal_au, p.terminal_au, 0};
+    add(tau, 8);
+    int zero = 0;
+    add(&zero, 1);
+  }
   std::vector<double> bulge(64);
   for (int u = 0; u < 64; u++) // gapped_extension.cpp:439
     bulge[u] = u <= 30 ? (double)p.bulge37[u] : p.bulge37[30] + p.lxc37 * std::log(u / 30.);
@@ -127,8 +140,18 @@ int prb_search_const_upload(prb_ctx *ctx) {
   if ((rc = m->bulge.ensure(bulge.size() * 8))) return rc;
   PRB_HIP(hipMemcpy(m->ints.p, ints.data(), ints.size() * 4, hipMemcpyHostToDevice));
   PRB_HIP(hipMemcpy(m->bulge.p, bulge.data(), bulge.size() * 8, hipMemcpyHostToDevice));
+  std::vector<double> d100(4096);
+  for (int z = 0; z < 4096; z++) d100[z] = (double)(z - 2048) / 100.0;
+  if ((rc = m->div100.ensure(d100.size() * 8))) return rc;
+  PRB_HIP(hipMemcpy(m->div100.p, d100.data(), d100.size() * 8, hipMemcpyHostToDevice));
+  for (int t = 0; t < 7; t++)
+    if (p.rtype[t] != (t == 0 ? 0 : ((t - 1) ^ 1) + 1)) {
+      set_error("parameter file: rtype is not the expected pair-type involution");
+      return PRB_ERR_ARG;
+    }
   const int32_t *b = m->ints.as<int32_t>();
   SearchConst &v = m->view;
+  v.tab = b;
   v.stack37 = b + o_stack;
   v.internal37 = b + o_int;
   v.mismatchI37 = b + o_mm;
@@ -138,11 +161,13 @@ int prb_search_const_upload(prb_ctx *ctx) {
   v.dangle5 = b + o_d5;
   v.dangle3 = b + o_d3;
   v.bulge = m->bulge.as<double>();
+  v.div100 = m->div100.as<double>();
+  v.bp_rows = 0;
+  for (int a = 1; a < 5; a++)
+    for (int c = 0; c < 5; c++) v.bp_rows |= (uint64_t)(p.bp_pair[a][c] & 7) << (15 * (a - 1) + 3 * c);
   v.terminal_au = p.terminal_au;
   for (int a = 0; a < 5; a++)
     for (int c = 0; c < 5; c++) v.bp_pair[a * 5 + c] = (unsigned char)p.bp_pair[a][c];
-  for (int t = 0; t < 7; t++) v.rtype[t] = (unsigned char)p.rtype[t];
-  v.rtype[7] = 0;
   return PRB_OK;
 }
 
@@ -151,6 +176,7 @@ void prb_search_const_free(prb_ctx *ctx) {
     auto *m = static_cast<SearchConstMem *>(ctx->search_const);
     m->ints.release();
     m->bulge.release();
+    m->div100.release();
     delete m;
     ctx->search_const = nullptr;
   }
@@ -647,9 +673,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // ---- gapped extension ----
   if ((rc = w.hitsC.ensure(hits_bytes(nung)))) return rc;
   HitSoA G = carve_hits(w.hitsC, nung);
-  if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4))) return rc;
+  if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4)) ||
+      (rc = w.ntrace.ensure((size_t)nung * 4)))
+    return rc;
   int64_t hs_slow = 0;
-  const bool force_wave = getenv("PRB_FORCE_WAVE_GAPPED") != nullptr; // testing: bypass the LDS kernel
+  const bool force_wave = getenv("PRB_FORCE_WAVE_GAPPED") != nullptr; // testing: bypass the LDS kernels
+  const bool skip_tier1 = getenv("PRB_GAPPED_SKIP_TIER1") != nullptr; // testing: everything through tier 2
   auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
     gs.cap_diag = cap_diag;
     gs.cap_rec = cap_rec;
@@ -664,7 +693,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // Slow path: wave-per-hit kernel with its state in HBM scratch, for the hit list `list`
   // (indices into U), growing the scratch 4x for hits that still overflow.  mode 0 writes G; modes 1/2 use
   // cnt_dev / off_dev (indexed by position in `list`).
-  auto run_slow = [&](int mode, std::vector<uint32_t> list, int32_t *cnt_dev, const int64_t *off_dev) -> int {
+  auto run_slow = [&](int mode, std::vector<uint32_t> list, const int64_t *off_dev) -> int {
     int cap_diag = 512, cap_rec = 2048;
     if (mode != 0) { // caps known to suffice for every hit seen so far
       cap_diag = std::max(512, ctx->max_gap_caps);
@@ -678,8 +707,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = w.subset2.ensure((size_t)m * 4))) return rc;
       PRB_HIP(hipMemcpyAsync(w.subset2.p, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
       PRB_HIP(launch_gapped_wave(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, gs, mode,
-                            mode == 0 ? w.overflow.as<uint8_t>() : nullptr, w.first.as<uint8_t>(), cnt_dev, off_dev,
-                            w.bpOut.as<int32_t>(), ctx->stream));
+                                 mode == 0 ? w.overflow.as<uint8_t>() : nullptr, w.first.as<uint8_t>(),
+                                 mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream));
       ctx->timers["gapped_slow"].launches++;
       if (mode != 0) break;
       ov.resize((size_t)m);
@@ -700,29 +729,53 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     }
     return PRB_OK;
   };
-  // extends every hit of U into G: cooperative LDS kernel first, slow path for its overflows
+  // extends every hit of U into G: LDS kernel tier 1, its overflows through tier 2, the rest
+  // through the wave kernel.  tier_of[x] remembers which one completed hit x.
+  std::vector<uint8_t> tier_of;
   auto run_gapped = [&](int64_t n) -> int {
-    std::vector<uint8_t> ov((size_t)n, 1);
-    if (!force_wave) {
-    if ((rc = ctx->time_begin())) return rc;
-    PRB_HIP(launch_gapped_lds(U, G, n, nullptr, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.first.as<uint8_t>(),
-                              nullptr, nullptr, nullptr, ctx->stream));
-    if ((rc = ctx->time_end("gapped", 1))) return rc;
-    PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    PRB_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    tier_of.assign((size_t)n, 3);
     std::vector<uint32_t> list;
-    for (int64_t i = 0; i < n; i++)
-      if (ov[i]) list.push_back((uint32_t)i);
-    hs_slow += (int64_t)list.size();
+    if (!force_wave) {
+      std::vector<uint8_t> ov((size_t)n, 1);
+      if (!skip_tier1) {
+        if ((rc = ctx->time_begin())) return rc;
+        PRB_HIP(launch_gapped_lds(U, G, n, nullptr, qb->view, pd, sc, eo, 0, 1, w.overflow.as<uint8_t>(),
+                                  w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), nullptr, nullptr, ctx->stream));
+        if ((rc = ctx->time_end("gapped", 1))) return rc;
+        PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        PRB_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      for (int64_t i = 0; i < n; i++) {
+        if (ov[i]) list.push_back((uint32_t)i);
+        else tier_of[i] = 1;
+      }
+      hs_slow += (int64_t)list.size();
+    } else {
+      for (int64_t i = 0; i < n; i++) list.push_back((uint32_t)i);
+    }
     if (list.empty()) return PRB_OK;
     if ((rc = ctx->time_begin())) return rc;
-    if ((rc = run_slow(0, std::move(list), nullptr, nullptr))) return rc;
+    if (skip_tier1) { // testing: the large-capacity LDS instantiation, then the wave kernel for its overflows
+      const int64_t m = (int64_t)list.size();
+      if ((rc = w.subset2.ensure((size_t)m * 4))) return rc;
+      PRB_HIP(hipMemcpyAsync(w.subset2.p, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+      PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 0, 2, w.overflow.as<uint8_t>(),
+                                w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), nullptr, nullptr, ctx->stream));
+      std::vector<uint8_t> ov2((size_t)m);
+      PRB_HIP(hipMemcpyAsync(ov2.data(), w.overflow.p, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      std::vector<uint32_t> rest;
+      for (int64_t i = 0; i < m; i++) {
+        if (ov2[i]) rest.push_back(list[i]);
+        else tier_of[list[i]] = 2;
+      }
+      list.swap(rest);
+    }
+    if (!list.empty() && (rc = run_slow(0, std::move(list), nullptr))) return rc;
     return ctx->time_end("gapped_slow", 0);
   };
   if ((rc = run_gapped(nung))) return rc;
   hs->slow_hits += hs_slow;
-  ctx->timers["gapped_slow"].launches += 0;
   ctx->slow_hits += hs_slow;
 
   // ---- final sort + filter ----
@@ -749,53 +802,52 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   {
     std::vector<uint32_t> pre((size_t)nfin); // index of each final hit's pre-gapped state in U
     PRB_HIP(hipMemcpyAsync(pre.data(), w.subset.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PRB_HIP(hipMemsetAsync(w.bpCount.p, force_wave ? 0xFF : 0, (size_t)(nfin + 1) * 4, ctx->stream));
-    if (!force_wave)
-      PRB_HIP(launch_gapped_lds(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, 1, nullptr, w.first.as<uint8_t>(),
-                                w.bpCount.as<int32_t>(), nullptr, nullptr, ctx->stream));
+    PRB_HIP(launch_bp_count(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.ntrace.as<int32_t>(),
+                            w.bpCount.as<int32_t>(), ctx->stream));
     std::vector<int32_t> cnt((size_t)nfin);
     PRB_HIP(hipMemcpyAsync(cnt.data(), w.bpCount.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
-    // hits beyond the LDS capacities: count (and later write) through the slow path
-    std::vector<uint32_t> slow_pos, slow_list;
-    for (int64_t i = 0; i < nfin; i++)
-      if (cnt[i] < 0) {
-        slow_pos.push_back((uint32_t)i);
-        slow_list.push_back(pre[i]);
+    // final hits whose extension needs tier 2 / the wave kernel (beyond the tier-1 capacities)
+    std::vector<uint32_t> pos2, list2, pos3, list3;
+    for (int64_t i = 0; i < nfin; i++) {
+      const uint8_t t = tier_of[pre[i]];
+      if (t == 2) {
+        pos2.push_back((uint32_t)i);
+        list2.push_back(pre[i]);
+      } else if (t == 3) {
+        pos3.push_back((uint32_t)i);
+        list3.push_back(pre[i]);
       }
-    if (!slow_list.empty()) {
-      if ((rc = w.bpCount2.ensure(slow_list.size() * 4)) || (rc = w.bpOff2.ensure(slow_list.size() * 8))) return rc;
-      if ((rc = ctx->time_end("traceback", 1))) return rc;
-      if ((rc = ctx->time_begin())) return rc;
-      if ((rc = run_slow(1, slow_list, w.bpCount2.as<int32_t>(), nullptr))) return rc;
-      if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
-      if ((rc = ctx->time_begin())) return rc;
-      std::vector<int32_t> c2(slow_list.size());
-      PRB_HIP(hipMemcpyAsync(c2.data(), w.bpCount2.p, c2.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      PRB_HIP(hipStreamSynchronize(ctx->stream));
-      for (size_t k = 0; k < c2.size(); k++) cnt[slow_pos[k]] = c2[k];
     }
     std::vector<int64_t> off((size_t)nfin + 1, 0);
-    for (int64_t i = 0; i < nfin; i++) {
-      if (cnt[i] < 0) {
-        set_error("internal error: traceback scratch overflow");
-        return PRB_ERR_STATE;
-      }
-      off[i + 1] = off[i] + cnt[i];
-    }
+    for (int64_t i = 0; i < nfin; i++) off[i + 1] = off[i] + cnt[i];
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
     PRB_HIP(hipMemcpyAsync(w.bpOff.p, off.data(), (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (!force_wave)
-      PRB_HIP(launch_gapped_lds(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, 2, nullptr, w.first.as<uint8_t>(),
-                                nullptr, w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
-    if (!slow_list.empty()) {
-      std::vector<int64_t> o2(slow_list.size());
-      for (size_t k = 0; k < o2.size(); k++) o2[k] = off[slow_pos[k]];
-      PRB_HIP(hipMemcpyAsync(w.bpOff2.p, o2.data(), o2.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!force_wave && !skip_tier1)
+      PRB_HIP(launch_gapped_lds(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, 2, 1, nullptr,
+                                w.first.as<uint8_t>(), nullptr, w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
+    if (!list2.empty() || !list3.empty()) {
       if ((rc = ctx->time_end("traceback", 1))) return rc;
       if ((rc = ctx->time_begin())) return rc;
-      if ((rc = run_slow(2, slow_list, nullptr, w.bpOff2.as<int64_t>()))) return rc;
+      if (!list2.empty()) {
+        std::vector<int64_t> o2(list2.size());
+        for (size_t k = 0; k < o2.size(); k++) o2[k] = off[pos2[k]];
+        if ((rc = w.bpOff2.ensure(o2.size() * 8)) || (rc = w.subset2.ensure(list2.size() * 4))) return rc;
+        PRB_HIP(hipMemcpyAsync(w.bpOff2.p, o2.data(), o2.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        PRB_HIP(hipMemcpyAsync(w.subset2.p, list2.data(), list2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        PRB_HIP(launch_gapped_lds(U, G, (int64_t)list2.size(), w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, 2, nullptr,
+                                  w.first.as<uint8_t>(), nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
+        PRB_HIP(hipStreamSynchronize(ctx->stream)); // o2 / list2 are reused below
+      }
+      if (!list3.empty()) {
+        std::vector<int64_t> o3(list3.size());
+        for (size_t k = 0; k < o3.size(); k++) o3[k] = off[pos3[k]];
+        if ((rc = w.bpOff2.ensure(o3.size() * 8))) return rc;
+        PRB_HIP(hipMemcpyAsync(w.bpOff2.p, o3.data(), o3.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = run_slow(2, list3, w.bpOff2.as<int64_t>()))) return rc;
+        PRB_HIP(hipStreamSynchronize(ctx->stream));
+      }
       if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
       if ((rc = ctx->time_begin())) return rc;
     }
@@ -832,9 +884,9 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     return PRB_ERR_STATE;
   }
   if (opts->drop_out_w_gap < 0 || opts->drop_out_w_gap > 30 || opts->drop_out_wo_gap < 1 || opts->drop_out_wo_gap > 15 ||
-      opts->min_helix_length < 1 || opts->max_seed_length < 1) {
+      opts->min_helix_length < 1 || opts->min_helix_length > 16 || opts->max_seed_length < 1) {
     set_error("unsupported option: need 0 <= -x <= 30, 1 <= -y <= 15 (beyond that the reference reads outside its "
-              "31-entry loop tables), -m >= 1, -l >= 1");
+              "31-entry loop tables), 1 <= -m <= 16, -l >= 1");
     return PRB_ERR_ARG;
   }
   PRB_HIP(hipSetDevice(ctx->device));

@@ -14,9 +14,9 @@
 // kept redundantly in every lane.  The reference's growing 100x100 Cell matrix never exists.
 //
 // Two instantiations:
-//   k_gapped_lds   G = 16, state in LDS (3.3 KB per hit; 16 hits per workgroup): > 99.8 % of hits
-//   k_gapped_wave  G = 64, state in HBM scratch sized at run time: the rest (extensions longer
-//                  than 64 anti-diagonals or with more than 128 filled cells per direction)
+//   k_gapped_lds   G = 16, state in LDS; tier 1 (64 anti-diagonals, 96 cells: 2.4 KB per hit, 64 hits
+//                  per CU) takes ~98.6 % of the hits, tier 2 (128, 448: 9.6 KB per hit) the next ~1.4 %
+//   k_gapped_wave  G = 64, state in HBM scratch sized at run time: the rest
 // Why: an extension is small (median 16 anti-diagonals, ~10 filled cells per direction) but its
 // cell list is re-read for every filled cell; per-thread scratch in HBM made every access a
 // dependent HBM round trip (r01 baseline profile: 117 ns/hit; LDS form: 19 ns/hit).
@@ -29,42 +29,70 @@ namespace prb {
 
 namespace {
 
-constexpr int kCapD = 64;  // anti-diagonals per direction held in LDS
-constexpr int kCapR = 128; // filled cells per direction held in LDS
 constexpr int kLdsGroup = 16;
-constexpr int kLdsGroupsPerBlock = 16;
-
-// filled cell r: i | j << 16 | type << 32 | ptype << 36 | pred << 40
-__device__ __forceinline__ uint64_t pack(int i, int j, int pred, int type, int ptype) {
-  return (uint64_t)(uint32_t)i | ((uint64_t)(uint32_t)j << 16) | ((uint64_t)type << 32) | ((uint64_t)ptype << 36) |
-         ((uint64_t)(uint32_t)pred << 40);
-}
-__device__ __forceinline__ int rec_i(uint64_t v) { return (int)(v & 0xFFFF); }
-__device__ __forceinline__ int rec_j(uint64_t v) { return (int)((v >> 16) & 0xFFFF); }
-__device__ __forceinline__ int rec_type(uint64_t v) { return (int)((v >> 32) & 0xF); }
-__device__ __forceinline__ int rec_pred(uint64_t v) { return (int)(v >> 40); }
-
-struct LdsState {
-  double eq[kCapD], ed[kCapD];
-  double hyb[kCapR];
-  uint64_t info[kCapR];
-  uint8_t ptab[3][kCapD + 16];
+constexpr int kStage = 16; // extension lengths whose accessibility terms are staged at a time
+// LDS tiers: (anti-diagonals, filled cells) per direction, groups (= hits) per workgroup
+struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads per CU
+  static constexpr int kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3;
 };
-struct LdsStore {
-  LdsState &s;
-  __device__ __forceinline__ int cap_d() const { return kCapD; }
-  __device__ __forceinline__ int cap_r() const { return kCapR; }
+struct Tier2 { // 9.6 KB per hit, 2 workgroups of 128 threads per CU
+  static constexpr int kCapD = 128, kCapR = 448, kGroups = 8, kWavesPerSimd = 1;
+};
+
+// A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
+// ptype = Cell::type); the LDS form packs it into 32 bits, the HBM form into 64.
+struct Rec32 {
+  using word = uint32_t; // i:7 | j:7 | pred:7 | type:3 | ptype:3
+  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
+    return (word)i | ((word)j << 7) | ((word)pred << 14) | ((word)type << 21) | ((word)ptype << 24);
+  }
+  static __device__ __forceinline__ int i(word v) { return v & 0x7F; }
+  static __device__ __forceinline__ int j(word v) { return (v >> 7) & 0x7F; }
+  static __device__ __forceinline__ int pred(word v) { return (v >> 14) & 0x7F; }
+  static __device__ __forceinline__ int type(word v) { return (v >> 21) & 7; }
+};
+struct Rec64 {
+  using word = uint64_t; // i:16 | j:16 | type:4 | ptype:4 | pred:24
+  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
+    return (word)(uint32_t)i | ((word)(uint32_t)j << 16) | ((word)type << 32) | ((word)ptype << 36) |
+           ((word)(uint32_t)pred << 40);
+  }
+  static __device__ __forceinline__ int i(word v) { return (int)(v & 0xFFFF); }
+  static __device__ __forceinline__ int j(word v) { return (int)((v >> 16) & 0xFFFF); }
+  static __device__ __forceinline__ int pred(word v) { return (int)(v >> 40); }
+  static __device__ __forceinline__ int type(word v) { return (int)((v >> 32) & 0xF); }
+};
+static_assert(Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127, "Rec32 field widths");
+
+template <class T, class Rec> struct LdsState {
+  double eq[T::kCapD], ed[T::kCapD];
+  double hyb[T::kCapR];
+  typename Rec::word info[T::kCapR];
+  float stage[6][kStage];       // accessibility terms of the next kStage extension lengths
+  uint8_t ptab[3][T::kCapD + 16];
+  uint8_t qb[T::kCapD + 16], db[T::kCapD + 16]; // bases along the extension, 0 = end of sequence / masked
+};
+template <class T, class Rec> struct LdsStore {
+  using R = Rec;
+  LdsState<T, Rec> &s;
+  __device__ __forceinline__ int cap_d() const { return T::kCapD; }
+  __device__ __forceinline__ int cap_r() const { return T::kCapR; }
   __device__ __forceinline__ double &eq(int i) const { return s.eq[i]; }
   __device__ __forceinline__ double &ed(int i) const { return s.ed[i]; }
   __device__ __forceinline__ double &hyb(int r) const { return s.hyb[r]; }
-  __device__ __forceinline__ uint64_t &info(int r) const { return s.info[r]; }
+  __device__ __forceinline__ typename Rec::word &info(int r) const { return s.info[r]; }
   __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return s.ptab[row][i]; }
-  __device__ __forceinline__ int ptab_len() const { return kCapD + 16; }
+  __device__ __forceinline__ int ptab_len() const { return T::kCapD + 16; }
+  __device__ __forceinline__ uint8_t &qb(int t) const { return s.qb[t]; }
+  __device__ __forceinline__ uint8_t &db(int t) const { return s.db[t]; }
+  __device__ __forceinline__ float &stage(int k, int t) const { return s.stage[k][t]; }
 };
 struct HbmStore { // one block of the scratch per group
+  using R = Rec64;
   double *eq_, *ed_, *hyb_;
   uint64_t *info_;
-  uint8_t *ptab_;
+  uint8_t *ptab_, *qb_, *db_;
+  float *stage_;
   int capd, capr;
   __device__ __forceinline__ int cap_d() const { return capd; }
   __device__ __forceinline__ int cap_r() const { return capr; }
@@ -74,6 +102,9 @@ struct HbmStore { // one block of the scratch per group
   __device__ __forceinline__ uint64_t &info(int r) const { return info_[r]; }
   __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return ptab_[(size_t)row * (capd + 16) + i]; }
   __device__ __forceinline__ int ptab_len() const { return capd + 16; }
+  __device__ __forceinline__ uint8_t &qb(int t) const { return qb_[t]; }
+  __device__ __forceinline__ uint8_t &db(int t) const { return db_[t]; }
+  __device__ __forceinline__ float &stage(int k, int t) const { return stage_[k * kStage + t]; }
 };
 
 // State traffic inside a group is produced and consumed by lanes of ONE wavefront; its
@@ -97,11 +128,15 @@ struct DirResult {
 };
 
 // GappedExtension::extension (gapped_extension.cpp:71-319) for one direction, by a group of G lanes.
+// Everything the anti-diagonal loop touches is staged on chip first: the bases along both
+// strands (so GetBPType / CheckHelixLength / LoopEnergy never go back to HBM), and the
+// accessibility terms kStage extension lengths at a time.
 template <int G, bool kLds, class Store>
 __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, HitState &h, int flag, const uint8_t *qs,
-                                      const float *qacc, const float *qcond, const uint8_t *ds, const float *dacc,
-                                      const float *dcond, const Store &S, int gl /* lane in group */, int gbase /* first lane of the group in its wavefront */) {
-  const int MAXE = 100000;
+                                      int qn, const float *qacc, const float *qcond, const uint8_t *ds, int64_t dn,
+                                      const float *dacc, const float *dcond, const Store &S, int gl /* lane in group */,
+                                      int gbase /* first lane of the group in its wavefront */) {
+  using R = typename Store::R;
   const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
   double min_e = h.e_tot;
   const double first_a = h.e_acc;
@@ -115,7 +150,6 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
     q_start = h.q_sp + h.q_len - 1;
     db_start = (int64_t)h.db_sp + h.db_len - 1;
   }
-  int max_q = MAXE, max_d = MAXE;
   const int id_start = h.id_start, id_end = id_start + h.db_len - 1;
   int min_q_start = q_start;
   int64_t min_db_start = db_start;
@@ -124,18 +158,38 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
   int length = 0, min_length = 0, best = 0;
   bool overflow = false;
 
-  int type0 = bp_type(sc, get_char(qs, q_start), get_char(ds, db_start));
-  if (flag == 0) type0 = sc.rtype[type0];
-  for (int t = gl; t < 3 * S.ptab_len(); t += G) S.ptab(0, t) = 0;
+  // bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407);
+  // the first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154)
+  const int wn = S.ptab_len();
+  int tq0 = wn, td0 = wn;
+  for (int t = gl; t < wn; t += G) {
+    const int64_t qp = flag == 0 ? (int64_t)q_start - t : (int64_t)q_start + t;
+    const int64_t dp = flag == 0 ? db_start - t : db_start + t;
+    const int qc = (qp >= 0 && qp < qn) ? get_char(qs, qp) : 0;
+    const int dc = (dp >= 0 && dp < dn) ? get_char(ds, dp) : 0;
+    S.qb(t) = (uint8_t)qc;
+    S.db(t) = (uint8_t)dc;
+    if (t >= 1 && qc == 0 && t < tq0) tq0 = t;
+    if (t >= 1 && dc == 0 && t < td0) td0 = t;
+  }
+  for (int t = gl; t < 3 * wn; t += G) S.ptab(0, t) = 0;
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) {
+    const int a = __shfl_xor(tq0, m), b = __shfl_xor(td0, m);
+    tq0 = a < tq0 ? a : tq0;
+    td0 = b < td0 ? b : td0;
+  }
   group_sync<kLds>();
+  int type0 = bp_type(sc, S.qb(0), S.db(0));
+  if (flag == 0) type0 = rtype_of(type0);
   if (gl == 0) {
     S.hyb(0) = min_e;
-    S.info(0) = pack(0, 0, 0, type0, type0);
+    S.info(0) = R::pack(0, 0, 0, type0, type0);
     S.ptab(0, 0) = (uint8_t)type0; // cell (0,0) lies on anti-diagonal 0
   }
   group_sync<kLds>();
   int nrec = 1, lo = 0;
-  double eq_prev = 0, ed_prev = 0;
+  double acc_prev = 0; // lane 0: eq[length-2]; lane 1 (or 0 when G == 1): ed[length-2]
 
   for (;;) {
     length++;
@@ -143,39 +197,65 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
       overflow = true;
       break;
     }
-    if (flag == 0) {
-      if (max_q == MAXE && (q_start - length < 0 || qs[q_start - length] < 2)) max_q = length - 1;
-      if (max_d == MAXE && (db_start - length < 0 || ds[db_start - length] < 2)) max_d = length - 1;
-    } else {
-      if (max_q == MAXE && qs[q_start + length] < 2) max_q = length - 1;
-      if (max_d == MAXE && ds[db_start + length] < 2) max_d = length - 1;
-    }
-    // cumulative accessibility change of the extension (:156-212), same value in every lane
-    if (max_q == MAXE) {
-      double v;
-      if (flag == 0) {
-        const int t = q_start - length;
-        if (length == 1) v = qacc[t] - qacc[t + 1] + qcond[t + delta];
-        else v = eq_prev + qacc[t] - qacc[t + 1] + qcond[t + delta];
-      } else {
-        if (length == 1) v = qcond[q_start + length];
-        else v = eq_prev + qcond[q_start + length];
+    // max_q_extension / max_db_extension as the reference has them after its checks at this length
+    const bool q_open = length < tq0, d_open = length < td0;
+    const int max_q = q_open ? 100000 : tq0 - 1, max_d = d_open ? 100000 : td0 - 1;
+    // cumulative accessibility change of the extension (:156-212), kStage lengths at a time:
+    // the terms are fetched in parallel, the sums are sequential (lane 0: query side, lane 1: db side)
+    if ((length - 1) % kStage == 0) {
+      if (gl < kStage) {
+        const int len = length + gl;
+        if (len < tq0) {
+          if (flag == 0) {
+            const int t = q_start - len;
+            S.stage(0, gl) = qacc[t];
+            S.stage(1, gl) = qacc[t + 1];
+            S.stage(2, gl) = qcond[t + delta];
+          } else {
+            S.stage(0, gl) = qcond[q_start + len];
+          }
+        }
+        if (len < td0) {
+          if (flag == 0) {
+            S.stage(3, gl) = dcond[id_end + len];
+          } else {
+            const int t = id_start - len;
+            S.stage(3, gl) = dacc[t];
+            S.stage(4, gl) = dacc[t + 1];
+            S.stage(5, gl) = dcond[t + delta];
+          }
+        }
       }
-      eq_prev = v;
-      if (gl == 0) S.eq(length - 1) = v;
-    }
-    if (max_d == MAXE) {
-      double v;
-      if (flag == 0) {
-        if (length == 1) v = dcond[id_end + length];
-        else v = ed_prev + dcond[id_end + length];
-      } else {
-        const int t = id_start - length;
-        if (length == 1) v = dacc[t] - dacc[t + 1] + dcond[t + delta];
-        else v = ed_prev + dacc[t] - dacc[t + 1] + dcond[t + delta];
+      group_sync<kLds>();
+      if (gl == 0) {
+        for (int k = 0; k < kStage && length + k < tq0 && length + k <= S.cap_d(); k++) {
+          const int len = length + k;
+          double v;
+          if (flag == 0) {
+            if (len == 1) v = S.stage(0, k) - S.stage(1, k) + S.stage(2, k); // float arithmetic, as the reference
+            else v = acc_prev + S.stage(0, k) - S.stage(1, k) + S.stage(2, k);
+          } else {
+            if (len == 1) v = S.stage(0, k);
+            else v = acc_prev + S.stage(0, k);
+          }
+          acc_prev = v;
+          S.eq(len - 1) = v;
+        }
+      } else if (gl == 1) {
+        for (int k = 0; k < kStage && length + k < td0 && length + k <= S.cap_d(); k++) {
+          const int len = length + k;
+          double v;
+          if (flag == 0) {
+            if (len == 1) v = S.stage(3, k);
+            else v = acc_prev + S.stage(3, k);
+          } else {
+            if (len == 1) v = S.stage(3, k) - S.stage(4, k) + S.stage(5, k);
+            else v = acc_prev + S.stage(3, k) - S.stage(4, k) + S.stage(5, k);
+          }
+          acc_prev = v;
+          S.ed(len - 1) = v;
+        }
       }
-      ed_prev = v;
-      if (gl == 0) S.ed(length - 1) = v;
     }
     const int cur = length % 3, d2 = (length + 1) % 3; // d2 = (length - 2) mod 3
     // recycle the row of anti-diagonal length-3 for this one
@@ -184,8 +264,8 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
     // prune candidates with length - first - second - 2 > drop (:213-217): a prefix of the list
     if (length - 2 > drop) {
       while (lo < nrec) {
-        const uint64_t v = S.info(lo);
-        if (length - rec_i(v) - rec_j(v) - 2 > drop) lo++;
+        const auto v = S.info(lo);
+        if (length - R::i(v) - R::j(v) - 2 > drop) lo++;
         else break;
       }
     }
@@ -196,13 +276,15 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
       const int i = i0 + gl, j = length - i;
       int type1 = 0;
       if (i <= i_hi) {
-        // CheckHelixLength (:342-364)
-        type1 = ext_bp_type(sc, flag, qs, ds, q_start, db_start, i, j, 0);
+        // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases
+        type1 = bp_type(sc, S.qb(i), S.db(j));
+        if (flag == 1) type1 = rtype_of(type1);
         if (type1 != 0) {
           const int pt = S.ptab(d2, i - 1);
           if (pt == 0 || (wobble(type1) && wobble(pt))) {
             for (int x = 1; x <= min_helix - 1; x++) {
-              const int t = ext_bp_type(sc, flag, qs, ds, q_start, db_start, i, j, x);
+              int t = bp_type(sc, S.qb(i + x), S.db(j + x));
+              if (flag == 1) t = rtype_of(t);
               if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
                 type1 = 0;
                 break;
@@ -224,16 +306,18 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
         for (int k0 = lo; k0 < dstart; k0 += G) {
           const int k = k0 + gl;
           if (k < dstart) {
-            const uint64_t v = S.info(k);
-            const int ri = rec_i(v), rj = rec_j(v);
+            const auto v = S.info(k);
+            const int ri = R::i(v), rj = R::j(v);
             if (ri < ci && rj < cj) {
+              // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
+              // offsets (ri, rj) and (ci, cj) from the start
               double te;
               if (flag == 0)
-                te = loop_energy_gapped(sc, ctype, rec_type(v), q_start - ci, (int)(db_start - cj), q_start - ri,
-                                        (int)(db_start - rj), qs, ds);
+                te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, S.qb(ci - 1), S.db(cj - 1),
+                                      S.qb(ri + 1), S.db(rj + 1));
               else
-                te = loop_energy_gapped(sc, rec_type(v), ctype, q_start + ri, (int)(db_start + rj), q_start + ci,
-                                        (int)(db_start + cj), qs, ds);
+                te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, S.qb(ri + 1), S.db(rj + 1),
+                                      S.qb(ci - 1), S.db(cj - 1));
               te += S.hyb(k);
               if (te < bte) {
                 bte = te;
@@ -256,10 +340,10 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
           break;
         }
         if (lo >= dstart) bk = 0; // empty window: the reference reads stem_candidate[0] of an empty list
-        const int ptype = rec_type(S.info(bk));
+        const int ptype = R::type(S.info(bk));
         if (gl == 0) {
           S.hyb(nrec) = bte;
-          S.info(nrec) = pack(ci, cj, bk, sc.rtype[ctype], ptype);
+          S.info(nrec) = R::pack(ci, cj, bk, rtype_of(ctype), ptype);
           S.ptab(cur, ci) = (uint8_t)ptype;
         }
         const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;
@@ -283,7 +367,7 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
     }
     if (overflow) break;
     if (length - min_length >= drop) break;
-    if (max_q != MAXE && max_d != MAXE) break;
+    if (!q_open && !d_open) break;
   }
   DirResult r;
   r.overflow = overflow;
@@ -311,15 +395,18 @@ struct GapArgs {
   ExtOpts o;
   uint8_t *overflow;
   const uint8_t *first_flag;
-  int32_t *bp_count;
+  int32_t *bp_count; // mode 0: traced pairs (left + right) of hit x; k_bp_count: total pairs of list entry w
   const int64_t *bp_off;
   int32_t *bp_out;
 };
 
-// One hit (index w of the work list) by one group.  kMode 0: extend, write the hit to out;
-// 1: count the base pairs of the final alignment; 2: write them at bp_off[w].
+// One hit (index w of the work list) by one group.  kMode 0: extend, write the hit to out and
+// the number of traced-back pairs to bp_count[x]; 2: write the base pairs of the final
+// alignment at bp_off[w] (the extension is recomputed: only the ~3 % of hits that survive the
+// final filter are ever traced).
 template <int kMode, int G, bool kLds, class Store>
 __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, int gbase) {
+  using R = typename Store::R;
   const SearchConst &sc = a.sc;
   const int64_t x = a.subset ? (int64_t)a.subset[w] : w;
   const int query = a.in.query[x];
@@ -353,27 +440,27 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
   for (int flag = 0; flag < 2 && !ovf; flag++) {
     const int q_start = flag == 0 ? h.q_sp : h.q_sp + h.q_len - 1;
     const int64_t db_start = flag == 0 ? (int64_t)h.db_sp : (int64_t)h.db_sp + h.db_len - 1;
-    const DirResult r = extend_dir_group<G, kLds>(sc, a.o, h, flag, qs, qacc, qcond, ds, dacc, dcond, S, gl, gbase);
+    const DirResult r = extend_dir_group<G, kLds>(sc, a.o, h, flag, qs, qn, qacc, qcond, ds, a.pg.nchars, dacc, dcond, S, gl, gbase);
     ovf = r.overflow;
-    if (kMode != 0 && !ovf) {
+    if (!ovf) {
       // traceback (:300-308, :409-424): from the arg-min cell through the predecessors
       int cnt = 0;
-      for (int k = r.best; k != 0; k = rec_pred(S.info(k))) cnt++;
+      for (int k = r.best; k != 0; k = R::pred(S.info(k))) cnt++;
       if (flag == 0) nleft = cnt;
       else nright = cnt;
       if (kMode == 2 && gl == 0) {
         int t = 0;
-        for (int k = r.best; k != 0; k = rec_pred(S.info(k)), t++) {
-          const uint64_t v = S.info(k);
+        for (int k = r.best; k != 0; k = R::pred(S.info(k)), t++) {
+          const auto v = S.info(k);
           int64_t pos;
           int qv, dv;
           if (flag == 0) { // emitted outermost first = ascending positions
-            qv = q_start - rec_i(v);
-            dv = (int)(db_start - rec_j(v));
+            qv = q_start - R::i(v);
+            dv = (int)(db_start - R::j(v));
             pos = unsorted ? out0 + ndiag + t : out0 + t;
           } else { // emitted outermost first = descending positions
-            qv = q_start + rec_i(v);
-            dv = (int)(db_start + rec_j(v));
+            qv = q_start + R::i(v);
+            dv = (int)(db_start + R::j(v));
             pos = unsorted ? out0 + ndiag + nleft + t : out0 + nleft + ndiag + (cnt - 1 - t);
           }
           a.bp_out[2 * pos] = qv;
@@ -387,6 +474,7 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
   if (kMode == 0) {
     a.overflow[w] = ovf ? 1 : 0;
     if (!ovf) {
+      a.bp_count[x] = nleft + nright;
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
       const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, qn, ds, a.pg.nchars);
       const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, qs, qn,
@@ -407,8 +495,6 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
       a.out.e_hyb[x] = hy;
       a.out.e_tot[x] = e;
     }
-  } else if (kMode == 1) {
-    a.bp_count[w] = ovf ? -1 : ndiag + nleft + nright;
   } else if (!ovf) {
     int t = 0;
     const int64_t d0 = unsorted ? out0 : out0 + nleft;
@@ -421,14 +507,31 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
   }
 }
 
-template <int kMode> __global__ __launch_bounds__(kLdsGroup *kLdsGroupsPerBlock) void k_gapped_lds(GapArgs a) {
-  __shared__ LdsState lds[kLdsGroupsPerBlock];
+// total base pairs of list entry w = complementary positions of the ungapped diagonal
+// (GetBasePair, rna_interaction_search.cpp:371-385) + the pairs traced by the two extensions
+__global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const uint32_t *__restrict__ subset, QBatchDev qb,
+                                                  PageDev pg, SearchConst sc, const int32_t *__restrict__ ntrace,
+                                                  int32_t *bp_count) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  const int64_t x = subset ? (int64_t)subset[w] : w;
+  const uint8_t *qs = qb.enc + qb.off[in.query[x]] + in.q_sp[x];
+  const uint8_t *ds = pg.seqs + in.db_sp[x];
+  const int len = US(in.q_len[x]);
+  int c = 0;
+  for (int t = 0; t < len; t++) c += sc.bp_pair[(qs[t] - 1) * 5 + (ds[t] - 1)] != 0;
+  bp_count[w] = c + ntrace[x];
+}
+
+template <int kMode, class T, class Rec>
+__global__ __launch_bounds__(kLdsGroup *T::kGroups, T::kWavesPerSimd) void k_gapped_lds(GapArgs a) {
+  __shared__ LdsState<T, Rec> lds[T::kGroups];
   const int gl = threadIdx.x & (kLdsGroup - 1);
   const int gbase = (threadIdx.x & 63) & ~(kLdsGroup - 1);
   const int gid = threadIdx.x / kLdsGroup;
-  const LdsStore S{lds[gid]};
-  const int64_t ngroups = (int64_t)gridDim.x * kLdsGroupsPerBlock;
-  for (int64_t w = (int64_t)blockIdx.x * kLdsGroupsPerBlock + gid; w < a.n; w += ngroups)
+  const LdsStore<T, Rec> S{lds[gid]};
+  const int64_t ngroups = (int64_t)gridDim.x * T::kGroups;
+  for (int64_t w = (int64_t)blockIdx.x * T::kGroups + gid; w < a.n; w += ngroups)
     gapped_one<kMode, kLdsGroup, true>(a, w, S, gl, gbase);
 }
 
@@ -442,29 +545,37 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
   S.ed_ = S.eq_ + S.capd;
   S.hyb_ = S.ed_ + S.capd;
   S.info_ = reinterpret_cast<uint64_t *>(S.hyb_ + S.capr);
-  S.ptab_ = reinterpret_cast<uint8_t *>(S.info_ + S.capr);
+  S.stage_ = reinterpret_cast<float *>(S.info_ + S.capr);
+  S.ptab_ = reinterpret_cast<uint8_t *>(S.stage_ + 6 * kStage);
+  S.qb_ = S.ptab_ + 3 * ((size_t)S.capd + 16);
+  S.db_ = S.qb_ + S.capd + 16;
   for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) gapped_one<kMode, 64, false>(a, w, S, gl, 0);
 }
 
 } // namespace
 
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
-  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 16);
+  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 6 * kStage * 4 + 5 * ((size_t)cap_diag + 16);
   return (b + 255) & ~(size_t)255;
 }
 
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
-                             const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, uint8_t *overflow,
+                             const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off, int32_t *bp_out,
                              hipStream_t s) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, first_flag, bp_count, bp_off, bp_out};
-  const int64_t want = (n + kLdsGroupsPerBlock - 1) / kLdsGroupsPerBlock;
-  const int blocks = (int)std::min<int64_t>(want, 256 * 3 * 8); // several rounds of resident workgroups
-  const dim3 blk(kLdsGroup * kLdsGroupsPerBlock);
-  if (mode == 0) hipLaunchKernelGGL(k_gapped_lds<0>, dim3(blocks), blk, 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL(k_gapped_lds<1>, dim3(blocks), blk, 0, s, a);
-  else hipLaunchKernelGGL(k_gapped_lds<2>, dim3(blocks), blk, 0, s, a);
+  if (tier == 1) {
+    const int64_t want = (n + Tier1::kGroups - 1) / Tier1::kGroups;
+    const dim3 grid((unsigned)std::min<int64_t>(want, 256 * 4 * 8)), blk(kLdsGroup * Tier1::kGroups);
+    if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, Tier1, Rec32>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_gapped_lds<2, Tier1, Rec32>), grid, blk, 0, s, a);
+  } else {
+    const int64_t want = (n + Tier2::kGroups - 1) / Tier2::kGroups;
+    const dim3 grid((unsigned)std::min<int64_t>(want, 256 * 2 * 8)), blk(kLdsGroup * Tier2::kGroups);
+    if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, Tier2, Rec64>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_gapped_lds<2, Tier2, Rec64>), grid, blk, 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -476,8 +587,15 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
   GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, first_flag, bp_count, bp_off, bp_out};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
-  else if (mode == 1) hipLaunchKernelGGL(k_gapped_wave<1>, dim3(blocks), dim3(64), 0, s, a, scratch);
   else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);
+  return hipGetLastError();
+}
+
+hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
+                           const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bp_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, subset, qb, pg, sc, ntrace,
+                     bp_count);
   return hipGetLastError();
 }
 

@@ -16,24 +16,38 @@ __device__ __forceinline__ int get_char(const uint8_t *s, int64_t i) {          
   unsigned c = s[i];
   return c < 2 ? 0 : base_of(c);
 }
-__device__ __forceinline__ int bp_type(const SearchConst &sc, int a, int b) { return sc.bp_pair[a * 5 + b]; }
+__device__ __forceinline__ int bp_type(const SearchConst &sc, int a, int b) {
+  return a == 0 ? 0 : (int)((sc.bp_rows >> (15 * (a - 1) + 3 * b)) & 7);
+}
+__device__ __forceinline__ int rtype_of(int t) { return t == 0 ? 0 : ((t - 1) ^ 1) + 1; } // energy_par.hpp:26
+// z / 100.0 for an integer energy z (0.01 kcal/mol): table of the exact IEEE quotients
+__device__ __forceinline__ double div100(const SearchConst &sc, int z) {
+  return (unsigned)(z + 2048) < 4096u ? sc.div100[z + 2048] : (double)z / 100.0;
+}
 
 
-// GappedExtension::LoopEnergy, gapped_extension.cpp:426-473
+// GappedExtension::LoopEnergy, gapped_extension.cpp:426-473.  Every branch sums integers
+// (units of 0.01 kcal/mol) and divides by 100.0 once.
 __device__ __forceinline__ double loop_energy_gapped(const SearchConst &sc, int type, int type2, int i, int j, int p, int q,
                                                      const uint8_t *qs, const uint8_t *ds) {
   const int u1 = p - i - 1, u2 = q - j - 1;
-  if (u1 == 0 && u2 == 0) return (double)sc.stack37[type * 7 + type2] / 100.0;
+  if (u1 == 0 && u2 == 0) return div100(sc, sc.stack37[type * 7 + type2]);
   if (u1 == 0 || u2 == 0) {
     const int u = u1 == 0 ? u2 : u1;
-    double z = sc.bulge[u];
+    if (u > 30) { // logarithmic extrapolation (:439); not reachable while -x <= 30
+      double z = sc.bulge[u < 63 ? u : 63];
+      if (type > 2) z += sc.terminal_au;
+      if (type2 > 2) z += sc.terminal_au;
+      return z / 100.0;
+    }
+    int z = (int)sc.bulge[u];
     if (u == 1) {
       z += sc.stack37[type * 7 + type2];
     } else {
       if (type > 2) z += sc.terminal_au;
       if (type2 > 2) z += sc.terminal_au;
     }
-    return z / 100.0;
+    return div100(sc, z);
   }
   const int a = base_of(qs[i + 1]), b = base_of(ds[j + 1]), c = base_of(qs[p - 1]), d = base_of(ds[q - 1]);
   int z;
@@ -42,7 +56,40 @@ __device__ __forceinline__ double loop_energy_gapped(const SearchConst &sc, int 
   else if (u1 == 2 && u2 == 1) z = sc.int21[(((type2 * 8 + type) * 5 + d) * 5 + a) * 5 + c];
   else if (u1 == 2 && u2 == 2) z = sc.int22[((((type * 8 + type2) * 5 + a) * 5 + c) * 5 + d) * 5 + b];
   else z = sc.internal37[u1 + u2] + sc.mismatchI37[(type * 5 + a) * 5 + b] + sc.mismatchI37[(type2 * 5 + d) * 5 + c];
-  return (double)z / 100.0;
+  return div100(sc, z);
+}
+
+// The same loop energy from the loop sizes and the four neighbour bases
+// a = q[i+1], b = db[j+1], c = q[p-1], d = db[q-1] (gapped_extension.cpp:449-456), written
+// without branches: every loop class is a sum of at most three entries of one integer
+// table (unused terms point at a zero entry), so the lanes of a group that look at loops of
+// different classes stay on one instruction stream.  Requires loop sizes <= 30 (-x <= 30).
+__device__ __forceinline__ double loop_energy_abcd(const SearchConst &sc, int type, int type2, int u1, int u2, int a, int b,
+                                                   int c, int d) {
+  using T = SearchTab;
+  const int tt = type * 8 + type2;
+  const int st = T::kStack + type * 7 + type2;
+  const bool z1 = u1 == 0, z2 = u2 == 0;
+  const int u = z1 ? u2 : u1;
+  // interior classes
+  const int i11 = T::kInt11 + (tt * 5 + a) * 5 + b;
+  const int i21a = T::kInt21 + ((tt * 5 + a) * 5 + d) * 5 + b;
+  const int i21b = T::kInt21 + (((type2 * 8 + type) * 5 + d) * 5 + a) * 5 + c;
+  const int i22 = T::kInt22 + (((tt * 5 + a) * 5 + c) * 5 + d) * 5 + b;
+  const bool c11 = u1 == 1 && u2 == 1, c12 = u1 == 1 && u2 == 2, c21 = u1 == 2 && u2 == 1, c22 = u1 == 2 && u2 == 2;
+  const bool special = c11 || c12 || c21 || c22;
+  int i1 = special ? (c11 ? i11 : c12 ? i21a : c21 ? i21b : i22) : T::kInternal + u1 + u2;
+  int i2 = special ? T::kZero : T::kMismatchI + (type * 5 + a) * 5 + b;
+  int i3 = special ? T::kZero : T::kMismatchI + (type2 * 5 + d) * 5 + c;
+  // stack / bulge classes
+  if (z1 || z2) {
+    const bool stack = z1 && z2;
+    i1 = stack ? st : T::kBulge + u;
+    i2 = stack ? T::kZero : (u == 1 ? st : T::kTau + type);
+    i3 = (stack || u == 1) ? T::kZero : T::kTau + type2;
+  }
+  const int z = sc.tab[i1] + sc.tab[i2] + sc.tab[i3];
+  return sc.div100[(z + 2048) & 4095];
 }
 
 // GetBPType, gapped_extension.cpp:321-338
@@ -57,7 +104,7 @@ __device__ __forceinline__ int ext_bp_type(const SearchConst &sc, int flag, cons
     dc = get_char(ds, db_start + j + x);
   }
   int t = bp_type(sc, qc, dc);
-  if (flag == 1) t = sc.rtype[t];
+  if (flag == 1) t = rtype_of(t);
   return t;
 }
 __device__ __forceinline__ bool wobble(int t) { return t == 3 || t == 4; }
@@ -80,7 +127,7 @@ __device__ __forceinline__ double dangle_energy_gapped(const SearchConst &sc, in
       if ((db_pos == dn - 1 || ds[db_pos + 1] == 0) && type > 2) x += sc.terminal_au;
     }
   }
-  return (double)x / 100.0;
+  return div100(sc, x);
 }
 
 

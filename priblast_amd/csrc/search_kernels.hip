@@ -107,7 +107,7 @@ __device__ __forceinline__ double loop_energy_ungapped(const SearchConst &sc, in
     else if (u1 == 2 && u2 == 2) z = sc.int22[((((type * 8 + type2) * 5 + a) * 5 + c) * 5 + d) * 5 + b];
     else z = sc.internal37[u1 + u2] + sc.mismatchI37[(type * 5 + a) * 5 + b] + sc.mismatchI37[(type2 * 5 + d) * 5 + c];
   }
-  return (double)z / 100.0;
+  return div100(sc, z);
 }
 
 __global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatchDev qb, PageDev pg, SearchConst sc,
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatch
     a += ta;
     const int type = bp_type(sc, base_of(qs[i]), base_of(ds[j]));
     if (type != 0) {
-      const int type2 = sc.rtype[bp_type(sc, base_of(qs[p]), base_of(ds[q]))];
+      const int type2 = rtype_of(bp_type(sc, base_of(qs[p]), base_of(ds[q])));
       const double le = loop_energy_ungapped(sc, type, type2, i, j, p, q, qs, ds);
       e += le;
       hy += le;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatch
     const double ta = qcond[k] + dacc[id_start] - dacc[id_start + 1] + dcond[id_start + delta];
     e += ta;
     a += ta;
-    const int type2 = sc.rtype[bp_type(sc, base_of(qs[k]), base_of(ds[l]))];
+    const int type2 = rtype_of(bp_type(sc, base_of(qs[k]), base_of(ds[l])));
     if (type2 != 0) {
       const int type = bp_type(sc, base_of(qs[r]), base_of(ds[s]));
       const double le = loop_energy_ungapped(sc, type, type2, r, s, k, l, qs, ds);

@@ -9,7 +9,24 @@ namespace prb {
 
 // Integer Turner tables (0.01 kcal/mol) as used by the extension stages
 // (ungapped_extension.cpp:157-186, gapped_extension.cpp:366-399, 426-473).
+// layout of the concatenated integer table `SearchConst::tab`
+struct SearchTab {
+  static constexpr int kStack = 0;                 // [7][7]
+  static constexpr int kInternal = kStack + 49;    // [31]
+  static constexpr int kMismatchI = kInternal + 31; // [7][5][5]
+  static constexpr int kInt11 = kMismatchI + 175;  // [8][8][5][5]
+  static constexpr int kInt21 = kInt11 + 1600;     // [8][8][5][5][5]
+  static constexpr int kInt22 = kInt21 + 8000;     // [8][8][5][5][5][5]
+  static constexpr int kDangle5 = kInt22 + 40000;  // [8][5]
+  static constexpr int kDangle3 = kDangle5 + 40;   // [8][5]
+  static constexpr int kBulge = kDangle3 + 40;     // [31] bulge37
+  static constexpr int kTau = kBulge + 31;         // [8] TerminalAU if pair type > 2 else 0
+  static constexpr int kZero = kTau + 8;           // one 0
+  static constexpr int kCount = kZero + 1;
+};
+
 struct SearchConst {
+  const int32_t *tab;       // SearchTab
   const int32_t *stack37;   // [7][7]
   const int32_t *internal37; // [31]
   const int32_t *mismatchI37; // [7][5][5]
@@ -19,9 +36,12 @@ struct SearchConst {
   const int32_t *dangle5;   // [8][5]
   const int32_t *dangle3;   // [8][5]
   const double *bulge;      // [64]: bulge37[u] for u <= 30, logarithmic extrapolation beyond
+  const double *div100;     // [4096]: (double)(z - 2048) / 100.0, the exact quotient the reference computes
   int32_t terminal_au;
+  // BP_pair (energy_par.hpp:17-23) packed 3 bits per entry, row a (1..4) at bit 15*(a-1);
+  // rtype (energy_par.hpp:26) is the involution ((t-1)^1)+1, checked on the host
+  uint64_t bp_rows;
   unsigned char bp_pair[25];
-  unsigned char rtype[8];
 };
 
 struct PageDev {
@@ -95,15 +115,18 @@ struct GapScratch {
 };
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
 // Gapped extension (gapped_lds.hip).  mode 0: extend hits (coords + energies) into `out`,
-// overflow[i] = 1 if the state capacity was too small; mode 1: count the base pairs of the final
-// alignment into bp_count[i] (-1 on overflow); mode 2: write them at bp_off[i].
-// launch_gapped_lds: 16 lanes per hit, state in LDS (fixed capacities).
+// overflow[i] = 1 if the state capacity was too small, bp_count[x] = pairs traced back by the
+// two extensions of hit x; mode 2: write the base pairs of list entry i at bp_off[i] (hits
+// beyond the capacity are skipped).  launch_bp_count: total pairs per list entry.
+// launch_gapped_lds: 16 lanes per hit, state in LDS (fixed capacities; tier 1 small, tier 2 large).
 // launch_gapped_wave: one wavefront per hit, state in the HBM scratch (`scratch.nthreads`
 // wavefronts, `bytes_per_thread` bytes each = gapped_wave_scratch_bytes(cap_diag, cap_rec)).
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
-                             const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, uint8_t *overflow,
+                             const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off, int32_t *bp_out,
                              hipStream_t s);
+hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
+                           const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s);
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
                               uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,

@@ -114,9 +114,10 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
                 assert f.read() == g.read(), (tag, ext)
 
 
-def test_wave_fallback_kernel_matches_lds_kernel(ctx, golden_dir, monkeypatch):
-    """Every hit through the wave-per-hit / HBM-scratch kernel (normally only the extensions that
-    outgrow the LDS capacities) must give the same final hits and base pairs."""
+@pytest.mark.parametrize("env", ["PRB_FORCE_WAVE_GAPPED", "PRB_GAPPED_SKIP_TIER1"])
+def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
+    """Every hit through the tier-2 LDS kernel / the wave-per-hit HBM-scratch kernel (normally only
+    the extensions that outgrow the tier-1 capacities) must give the same final hits and pairs."""
     from priblast_amd import capi
     for tag in ("c1", "mix"):
         names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
@@ -125,13 +126,13 @@ def test_wave_fallback_kernel_matches_lds_kernel(ctx, golden_dir, monkeypatch):
         qb.accessibility(db.W, db.delta)
         try:
             for page in range(db.npages):
-                monkeypatch.delenv("PRB_FORCE_WAVE_GAPPED", raising=False)
+                monkeypatch.delenv(env, raising=False)
                 h1, bp1, c1 = capi.search_page(ctx, qb, db, page)
-                monkeypatch.setenv("PRB_FORCE_WAVE_GAPPED", "1")
+                monkeypatch.setenv(env, "1")
                 h2, bp2, c2 = capi.search_page(ctx, qb, db, page)
                 assert c1 == c2
                 assert np.array_equal(h1, h2) and np.array_equal(bp1, bp2)
         finally:
-            monkeypatch.delenv("PRB_FORCE_WAVE_GAPPED", raising=False)
+            monkeypatch.delenv(env, raising=False)
             qb.close()
             db.close()
