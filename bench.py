@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
-STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_slow", "traceback", "traceback_slow")
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_slow", "traceback", "traceback_slow", "host_dfs")
 
 
 def parse():
@@ -149,8 +149,11 @@ def main():
         """one batch of a.queries queries of this rank through the whole hot path"""
         lo, hi = pdist.batch_slice(k, rank, world, a.queries)
         qs = qseqs[lo:hi]
+        t0 = time.perf_counter()
         qb = capi.QBatch(ctx, qs, db.repeat_flag)
+        t1 = time.perf_counter()
         qb.accessibility(db.W, db.delta)
+        t2 = time.perf_counter()
         total = [0, 0, 0]
         allhits = []
         for page in range(db.npages):
@@ -159,14 +162,21 @@ def main():
             for i in range(3):
                 total[i] += counts[i]
         qb.close()
+        t3 = time.perf_counter()
+        wall["qbatch (encode + SA + upload)"] += t1 - t0
+        wall["accessibility"] += t2 - t1
+        wall["search (DFS + GPU stages + download)"] += t3 - t2
         hits = np.concatenate(allhits) if allhits else np.zeros(0, capi.HIT_DTYPE)
         if world > 1:  # final hit gather over RCCL: counts, then padded POD records
             pdist.gather_hits(hits, 0, "cuda")
         return total
 
+    import collections
+    wall = collections.defaultdict(float)
     for k in range(a.warmup):
         step(k)
     ctx.reset_timers()
+    wall.clear()
     barrier()
     t = time.perf_counter()
     counts = [0, 0, 0]
@@ -211,6 +221,7 @@ def main():
                        "parallelism": f"queries sharded over {world} GPU(s), final hits gathered over RCCL"},
             "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
+            "host_wall_ms_per_step": {k: round(v / a.steps * 1e3, 1) for k, v in wall.items()},
             "roofline": {"bound": "hbm", "kernel": "k_gapped", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": gap_launch, "avg_launch_ms": gap_ms / max(gap_launch, 1),

@@ -135,7 +135,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
                     int32_t last_stage, prb_hitset **out);
 int64_t prb_hitset_size(const prb_hitset *hs);
 const prb_hit *prb_hitset_hits(const prb_hitset *hs);
-/* pairs (q, db) as int32[2], indexed by prb_hit.bp_offset */
+/* pairs (q, db) as int32[2], indexed by prb_hit.bp_offset.  With opts->output_style == 0
+ * (simplified output, which prints only the two ends of an interaction,
+ * rna_interaction_search.cpp:355-363) final hits carry exactly two pairs, the first and the
+ * last of the reference's list; with output_style == 1 they carry every pair. */
 const int32_t *prb_hitset_basepairs(const prb_hitset *hs, int64_t *count);
 /* number of hits per stage for the whole call: seeds, after ungapped+filter, final */
 void prb_hitset_counts(const prb_hitset *hs, int64_t counts[3]);

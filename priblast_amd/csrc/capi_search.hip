@@ -2,11 +2,14 @@
 // (SearchSeed / ExtendWithoutGap / ExtendWithGap, rna_interaction_search.cpp:264-320).
 #include <omp.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include <rocprim/rocprim.hpp>
 
@@ -35,12 +38,12 @@ struct PageMem {
 // buffers reused across prb_search_page calls
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
-      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, ntrace, bpCount, bpOff, bpOut, bpCount2, bpOff2,
+      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
       scanTmp;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &ntrace, &bpCount, &bpOff, &bpOut, &bpCount2, &bpOff2, &scanTmp})
+                      &subset, &subset2, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp})
       b->release();
   }
 };
@@ -97,6 +100,17 @@ struct prb_hitset {
 };
 
 namespace prb {
+// Host threads for the per-query host work (suffix arrays, seed DFS).  An explicit count,
+// because launchers such as torchrun export OMP_NUM_THREADS=1: PRB_HOST_THREADS, else
+// min(32, hardware threads).
+static int host_threads(int work_items) {
+  static const int cap = [] {
+    const char *e = getenv("PRB_HOST_THREADS");
+    int n = e ? atoi(e) : std::min(32, (int)std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1, n);
+  }();
+  return std::max(1, std::min(cap, work_items));
+}
 static SearchWs &ws_of(prb_ctx *ctx) {
   if (!ctx->search_ws) ctx->search_ws = new SearchWs();
   return *static_cast<SearchWs *>(ctx->search_ws);
@@ -369,7 +383,7 @@ int prb_qbatch_create(prb_ctx *ctx, int32_t nq, const char *seqs, const int64_t 
   qb->enc.assign((size_t)t, 0);
   qb->sa.assign((size_t)t, 0);
   Encoder enc(repeat_flag);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(host_threads(nq))
   for (int32_t q = 0; q < nq; q++) {
     const int64_t o = qb->off[q];
     const int32_t L = qb->len[q];
@@ -852,12 +866,25 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = ctx->time_begin())) return rc;
     }
     const size_t bp_base = hs->bp.size();
-    hs->bp.resize(bp_base + (size_t)total * 2);
-    if (total) PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpOut.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PRB_HIP(hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < nfin; i++) {
-      hs->hits[base + i].bp_count = cnt[i];
-      hs->hits[base + i].bp_offset = (int64_t)(bp_base / 2) + off[i];
+    if (opts.output_style == 0) {
+      // simplified output: only the first and the last pair of a hit are ever printed
+      if ((rc = w.bpEnds.ensure((size_t)nfin * 16))) return rc;
+      PRB_HIP(launch_bp_ends(w.bpOff.as<int64_t>(), nfin, w.bpOut.as<int32_t>(), w.bpEnds.as<int32_t>(), ctx->stream));
+      hs->bp.resize(bp_base + (size_t)nfin * 4);
+      PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpEnds.p, (size_t)nfin * 16, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      for (int64_t i = 0; i < nfin; i++) {
+        hs->hits[base + i].bp_count = 2;
+        hs->hits[base + i].bp_offset = (int64_t)(bp_base / 2) + 2 * i;
+      }
+    } else {
+      hs->bp.resize(bp_base + (size_t)total * 2);
+      if (total) PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpOut.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      for (int64_t i = 0; i < nfin; i++) {
+        hs->hits[base + i].bp_count = cnt[i];
+        hs->hits[base + i].bp_offset = (int64_t)(bp_base / 2) + off[i];
+      }
     }
   }
   return ctx->time_end("traceback", 2);
@@ -892,8 +919,9 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   PRB_HIP(hipSetDevice(ctx->device));
   const DbPage &pg = db->pages[page];
   // seed search proper: DFS over the two suffix arrays, per query, on the host
+  const auto t_dfs0 = std::chrono::steady_clock::now();
   std::vector<std::vector<SeedCandidate>> per_q((size_t)qb->nq);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads(qb->nq))
   for (int32_t q = 0; q < qb->nq; q++) {
     seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
              opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
@@ -908,6 +936,8 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     cands.insert(cands.end(), per_q[q].begin(), per_q[q].end());
   }
   qstart[qb->nq] = cands.size();
+  ctx->timers["host_dfs"].ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dfs0).count();
+  ctx->timers["host_dfs"].launches++;
   auto *hs = new prb_hitset();
   const char *env = getenv("PRB_SEARCH_PAIRS");
   const double budget = env ? atof(env) : 6.0e7;

@@ -591,6 +591,25 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
   return hipGetLastError();
 }
 
+// first and last pair of every list entry (all the simplified output prints,
+// rna_interaction_search.cpp:355-363): ends[4w..4w+3] = (q0, db0, qN, dbN)
+__global__ __launch_bounds__(256) void k_bp_ends(const int64_t *__restrict__ bp_off, int64_t n, const int32_t *__restrict__ bp,
+                                                 int32_t *ends) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  const int64_t a = bp_off[w], b = bp_off[w + 1] - 1;
+  ends[4 * w] = bp[2 * a];
+  ends[4 * w + 1] = bp[2 * a + 1];
+  ends[4 * w + 2] = bp[2 * b];
+  ends[4 * w + 3] = bp[2 * b + 1];
+}
+
+hipError_t launch_bp_ends(const int64_t *bp_off, int64_t n, const int32_t *bp, int32_t *ends, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bp_ends, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bp_off, n, bp, ends);
+  return hipGetLastError();
+}
+
 hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                            const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s) {
   if (n <= 0) return hipSuccess;

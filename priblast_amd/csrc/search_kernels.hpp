@@ -127,6 +127,7 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
                              hipStream_t s);
 hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                            const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s);
+hipError_t launch_bp_ends(const int64_t *bp_off, int64_t n, const int32_t *bp, int32_t *ends, hipStream_t s);
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
                               uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,

@@ -64,7 +64,7 @@ def test_stage_dumps(ctx, golden_dir, tag):
         for page in range(db.npages):
             per_stage = {}
             for stage in (1, 2, 3):
-                hits, bp, counts = capi.search_page(ctx, qb, db, page, last_stage=stage)
+                hits, bp, counts = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1), last_stage=stage)
                 per_stage[stage] = as_dicts(hits, bp)
             for rec in stg:
                 if rec["page"] != page:
@@ -127,12 +127,34 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
         try:
             for page in range(db.npages):
                 monkeypatch.delenv(env, raising=False)
-                h1, bp1, c1 = capi.search_page(ctx, qb, db, page)
+                h1, bp1, c1 = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
                 monkeypatch.setenv(env, "1")
-                h2, bp2, c2 = capi.search_page(ctx, qb, db, page)
+                h2, bp2, c2 = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
                 assert c1 == c2
                 assert np.array_equal(h1, h2) and np.array_equal(bp1, bp2)
         finally:
             monkeypatch.delenv(env, raising=False)
             qb.close()
             db.close()
+
+
+def test_simplified_style_returns_the_two_ends(ctx, golden_dir):
+    """output_style 0: exactly the first and last pair of the full list (hit 0 quirk included)."""
+    from priblast_amd import capi
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+    qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        for page in range(db.npages):
+            h1, bp1, _ = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
+            h0, bp0, _ = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=0))
+            assert len(h0) == len(h1)
+            for a, b in zip(h0, h1):
+                assert a["bp_count"] == 2
+                full = bp1[b["bp_offset"]:b["bp_offset"] + b["bp_count"]]
+                ends = bp0[a["bp_offset"]:a["bp_offset"] + 2]
+                assert np.array_equal(ends[0], full[0]) and np.array_equal(ends[1], full[-1])
+    finally:
+        qb.close()
+        db.close()
