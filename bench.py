@@ -52,6 +52,17 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(units_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_gapped_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per hit)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gapped_traffic.json")) as f:
+            per_unit = json.load(f)["bytes_per_unit"]["traffic_corrected_total"]
+        return per_unit * units_per_launch
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -222,8 +233,8 @@ def main():
             "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
             "host_wall_ms_per_step": {k: round(v / a.steps * 1e3, 1) for k, v in wall.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_gapped", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_gapped_lds<0, Tier1, Rec32>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(gap_units / max(gap_launch, 1)),
                          "launches": gap_launch, "avg_launch_ms": gap_ms / max(gap_launch, 1),
                          "units_per_launch": gap_units / max(gap_launch, 1), "bytes_per_unit": GAPPED_BYTES_PER_HIT},
         }
