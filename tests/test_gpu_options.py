@@ -1,0 +1,115 @@
+"""GPU parity under non-default `ris` options and on a larger case.
+
+* option sweeps (-l -e -f -g -x -y -m) are checked against the oracle's C restatement, which is
+  itself pinned to the reference on the default options (tests/test_oracle.py);
+* a 1 kb x 200 kb case is checked against the UNMODIFIED reference binary run on the box
+  (oracle/_ref, strict build) when it is present: sorted result lines, Id stripped."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import refdump
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from priblast_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+OPTION_SETS = [
+    dict(max_seed_length=8, hybrid_threshold=-4.0),
+    dict(interaction_threshold=-2.0, final_threshold=-5.0),
+    dict(drop_out_w_gap=4, drop_out_wo_gap=2),
+    dict(drop_out_w_gap=30, drop_out_wo_gap=12, min_helix_length=1),
+    dict(min_helix_length=5, final_threshold=-6.0),
+]
+ORACLE_NAMES = dict(max_seed_length="max_seed_length", hybrid_threshold="hybrid_thr", interaction_threshold="interaction_thr",
+                    final_threshold="final_thr", drop_out_w_gap="drop_w_gap", drop_out_wo_gap="drop_wo_gap",
+                    min_helix_length="min_helix")
+
+
+@pytest.mark.parametrize("kw", OPTION_SETS)
+def test_option_sweep_matches_oracle(ctx, oracle, golden_dir, kw):
+    from priblast_amd import capi
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+    odb = oracle.Db(os.path.join(golden_dir, "mixdb"))
+    qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    oopts = oracle.default_opts(**{ORACLE_NAMES[k]: v for k, v in kw.items()})
+    try:
+        total = 0
+        for page in range(db.npages):
+            hits, bp, counts = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1, **kw))
+            for q, s in enumerate(seqs):
+                _, _, gap = odb.stages(s, page, oopts)
+                mine = hits[hits["query"] == q]
+                assert len(mine) == len(gap), (kw, page, q)
+                key = lambda h: (h["db_sp"], h["q_sp"], -h["db_len"], -h["q_len"], h["e_tot"])
+                for a, b in zip(sorted(mine, key=key), sorted(gap, key=key)):
+                    for k in ("q_sp", "db_sp", "q_len", "db_len", "db_id", "db_id_start"):
+                        assert a[k] == b[k], (kw, page, q, k)
+                    assert float(a["e_tot"]) == b["e_tot"] and float(a["e_acc"]) == b["e_acc"]
+                    assert np.array_equal(bp[a["bp_offset"]:a["bp_offset"] + a["bp_count"]], b["bp"])
+                total += len(mine)
+        assert total > 0
+    finally:
+        qb.close()
+        db.close()
+        odb.close()
+
+
+def test_unsupported_options_fail_loudly(ctx, golden_dir):
+    from priblast_amd import capi
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+    qb = capi.QBatch(ctx, seqs[:1], db.repeat_flag)
+    try:
+        with pytest.raises(capi.PrbError):  # accessibilities not computed yet
+            capi.search_page(ctx, qb, db, 0)
+        qb.accessibility(db.W, db.delta)
+        with pytest.raises(capi.PrbError):  # beyond the reference's 31-entry loop tables
+            capi.search_page(ctx, qb, db, 0, capi.default_opts(drop_out_w_gap=31))
+        with pytest.raises(capi.PrbError):
+            ctx.accessibility(["ACGU" * 10], 200, 5)  # maximal span beyond the kernel's window
+    finally:
+        qb.close()
+        db.close()
+
+
+def test_1kb_vs_200kb_against_reference_binary(ctx, tmp_path):
+    """8 x 1 kb queries vs 200 x 1 kb database: the GPU command line and the unmodified reference
+    (built in the container, shipped to the box) must print the same result lines."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic
+    from priblast_amd import capi
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.strict")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    gen_synthetic.write_fasta(dbfa, gen_synthetic.gen(200, 1000, 1, "db"))
+    gen_synthetic.write_fasta(qfa, gen_synthetic.gen(8, 1000, 2, "q"))
+    # database by the GPU build; the reference reads it (the files are byte-compatible)
+    subprocess.run([capi.BIN_PATH, "db", "-i", dbfa, "-o", str(tmp_path / "db")], check=True)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    subprocess.run([ref, "ris", "-i", qfa, "-o", str(tmp_path / "ref.out"), "-d", str(tmp_path / "db"), "-p", str(tmp_path)],
+                   check=True, env=env, cwd=str(tmp_path))
+    subprocess.run([capi.BIN_PATH, "ris", "-i", qfa, "-o", str(tmp_path / "gpu.out"), "-d", str(tmp_path / "db")], check=True)
+
+    def body(p):
+        with open(p) as f:
+            return sorted(l.split(",", 1)[1] for l in f.read().splitlines()[3:])
+    a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
+    assert len(b) > 3000
+    assert a == b
