@@ -127,6 +127,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # host threads for the per-query host work (suffix arrays, seed DFS): share the box among the ranks
+    os.environ.setdefault("PRB_HOST_THREADS", str(max(8, min(64, host_cores() // max(world, 1)))))
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
