@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
-STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_slow", "traceback", "traceback_slow", "host_dfs")
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait")
 
 
 def parse():
@@ -128,7 +128,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # host threads for the per-query host work (suffix arrays, seed DFS): share the box among the ranks
-    os.environ.setdefault("PRB_HOST_THREADS", str(max(8, min(64, host_cores() // max(world, 1)))))
+    os.environ.setdefault("PRB_HOST_THREADS", str(max(8, min(32, host_cores() // max(world, 1)))))
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <numeric>
 #include <thread>
 
@@ -38,12 +40,12 @@ struct PageMem {
 // buffers reused across prb_search_page calls
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
-      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
+      state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
       scanTmp;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp})
       b->release();
   }
 };
@@ -562,6 +564,30 @@ static int filter_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, do
   return PRB_OK;
 }
 
+// Drops the hits whose energy is above `thr` (they cannot survive CheckRedundancy nor influence
+// it, see k_flag_not_above): out <- the kept hits of in, in order; *idx_out[i] = index in `in`.
+static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n, double thr, DevBuf &idxbuf, HitSoA out,
+                         int64_t *m) {
+  int rc;
+  *m = 0;
+  if (n == 0) return PRB_OK;
+  const size_t N = (size_t)n;
+  if ((rc = w.keep.ensure(N)) || (rc = idxbuf.ensure(N * 4)) || (rc = w.count.ensure(16))) return rc;
+  PRB_HIP(launch_flag_not_above(in.e_tot, n, thr, w.keep.as<uint8_t>(), ctx->stream));
+  size_t tmp = 0;
+  rocprim::counting_iterator<uint32_t> iota(0);
+  PRB_HIP(rocprim::select(nullptr, tmp, iota, w.keep.as<uint8_t>(), idxbuf.as<uint32_t>(), w.count.as<size_t>(), N, ctx->stream));
+  if ((rc = w.scanTmp.ensure(tmp))) return rc;
+  PRB_HIP(rocprim::select(w.scanTmp.p, tmp, iota, w.keep.as<uint8_t>(), idxbuf.as<uint32_t>(), w.count.as<size_t>(), N,
+                          ctx->stream));
+  size_t cnt = 0;
+  PRB_HIP(hipMemcpyAsync(&cnt, w.count.p, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  *m = (int64_t)cnt;
+  PRB_HIP(launch_gather_hits(in, idxbuf.as<uint32_t>(), out, *m, ctx->stream));
+  return PRB_OK;
+}
+
 static int download_hits(prb_ctx *ctx, const HitSoA &h, int64_t n, std::vector<prb_hit> &out) {
   const size_t base = out.size();
   out.resize(base + (size_t)n);
@@ -648,15 +674,23 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = ctx->time_begin())) return rc;
   PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, ctx->stream));
   if ((rc = ctx->time_end("ungapped", 1))) return rc;
+  // hits above the -f threshold are dropped before the sort (they cannot survive the filter)
   if ((rc = w.hitsB.ensure(hits_bytes(nseed)))) return rc;
-  HitSoA B = carve_hits(w.hitsB, nseed);
+  HitSoA A2 = carve_hits(w.hitsB, nseed);
+  int64_t m1 = 0;
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = compact_below(ctx, w, A, nseed, opts.interaction_threshold, w.cidx, A2, &m1))) return rc;
+  if ((rc = ctx->time_end("filter", 2))) return rc;
+  if (m1 == 0) return PRB_OK;
+  if ((rc = w.hitsC.ensure(hits_bytes(m1)))) return rc;
+  HitSoA B = carve_hits(w.hitsC, m1);
   uint32_t *perm = nullptr;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, A, B, nseed, qb->nq, &perm))) return rc;
+  if ((rc = sort_hits(ctx, w, A2, B, m1, qb->nq, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nung = 0;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = filter_hits(ctx, w, B, nseed, opts.interaction_threshold, &nung))) return rc;
+  if ((rc = filter_hits(ctx, w, B, m1, opts.interaction_threshold, &nung))) return rc;
   if ((rc = ctx->time_end("filter", 3))) return rc;
   hs->counts[1] += nung;
   if (nung == 0) return PRB_OK;
@@ -792,21 +826,30 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   hs->slow_hits += hs_slow;
   ctx->slow_hits += hs_slow;
 
-  // ---- final sort + filter ----
-  HitSoA S = carve_hits(w.hitsB, nung);
+  // ---- final sort + filter (hits above the -g threshold dropped first) ----
+  HitSoA G2 = carve_hits(w.hitsB, nung);
+  int64_t m2 = 0;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, G, S, nung, qb->nq, &perm))) return rc;
+  if ((rc = compact_below(ctx, w, G, nung, opts.final_threshold, w.cidx, G2, &m2))) return rc;
+  if ((rc = ctx->time_end("filter", 2))) return rc;
+  if (m2 == 0) return PRB_OK;
+  HitSoA S = carve_hits(w.hitsC, m2); // G is dead after the compaction
+  if ((rc = ctx->time_begin())) return rc;
+  if ((rc = sort_hits(ctx, w, G2, S, m2, qb->nq, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nfin = 0;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = filter_hits(ctx, w, S, nung, opts.final_threshold, &nfin))) return rc;
+  if ((rc = filter_hits(ctx, w, S, m2, opts.final_threshold, &nfin))) return rc;
   if ((rc = ctx->time_end("filter", 3))) return rc;
   hs->counts[2] += nfin;
   if (nfin == 0) return PRB_OK;
-  // final hits, and for each the index of its pre-gapped state in U (for the traceback)
-  HitSoA F = carve_hits(w.hitsC, nfin); // G is dead after the sort
+  // final hits, and for each the index of its pre-gapped state in U (for the traceback):
+  // final -> sorted position -> position in G2 -> index in U
+  HitSoA F = carve_hits(w.hitsB, nfin); // G2 is dead after the sort
   PRB_HIP(launch_gather_hits(S, w.surv.as<uint32_t>(), F, nfin, ctx->stream));
-  PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset.as<uint32_t>(), nfin, ctx->stream));
+  if ((rc = w.subset2.ensure((size_t)nfin * 4))) return rc;
+  PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset2.as<uint32_t>(), nfin, ctx->stream));
+  PRB_HIP(launch_gather_u32(w.cidx.as<uint32_t>(), w.subset2.as<uint32_t>(), w.subset.as<uint32_t>(), nfin, ctx->stream));
   const size_t base = hs->hits.size();
   if ((rc = download_hits(ctx, F, nfin, hs->hits))) return rc;
 
@@ -918,37 +961,63 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   }
   PRB_HIP(hipSetDevice(ctx->device));
   const DbPage &pg = db->pages[page];
-  // seed search proper: DFS over the two suffix arrays, per query, on the host
+  // Seed search proper: DFS over the two suffix arrays, per query, on host threads.  It runs
+  // in the background while the GPU already works on the first sub-batches: the consumer below
+  // only waits for the queries it is about to submit.
+  const int32_t nq = qb->nq;
+  std::vector<std::vector<SeedCandidate>> per_q((size_t)nq);
+  std::vector<double> qpairs((size_t)nq, 0);
+  std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[(size_t)nq]);
+  for (int32_t q = 0; q < nq; q++) done[q].store(0, std::memory_order_relaxed);
   const auto t_dfs0 = std::chrono::steady_clock::now();
-  std::vector<std::vector<SeedCandidate>> per_q((size_t)qb->nq);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads(qb->nq))
-  for (int32_t q = 0; q < qb->nq; q++) {
-    seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
-             opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
-    for (auto &c : per_q[q]) c.query = q;
-  }
-  std::vector<SeedCandidate> cands;
-  std::vector<size_t> qstart((size_t)qb->nq + 1, 0);
-  std::vector<double> qpairs((size_t)qb->nq, 0);
-  for (int32_t q = 0; q < qb->nq; q++) {
-    qstart[q] = cands.size();
-    for (auto &c : per_q[q]) qpairs[q] += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
-    cands.insert(cands.end(), per_q[q].begin(), per_q[q].end());
-  }
-  qstart[qb->nq] = cands.size();
-  ctx->timers["host_dfs"].ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dfs0).count();
-  ctx->timers["host_dfs"].launches++;
+  double dfs_ms = 0;
+  std::thread producer([&] {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads(nq))
+    for (int32_t q = 0; q < nq; q++) {
+      seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
+               opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
+      double pairs = 0;
+      for (auto &c : per_q[q]) {
+        c.query = q;
+        pairs += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
+      }
+      qpairs[q] = pairs;
+      done[q].store(1, std::memory_order_release);
+    }
+    dfs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dfs0).count();
+  });
+  auto wait_for = [&](int32_t q) {
+    while (!done[q].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  };
   auto *hs = new prb_hitset();
   const char *env = getenv("PRB_SEARCH_PAIRS");
   const double budget = env ? atof(env) : 6.0e7;
   int rc = PRB_OK;
-  for (int32_t q0 = 0; q0 < qb->nq && rc == PRB_OK;) {
+  std::vector<SeedCandidate> cands;
+  double wait_ms = 0;
+  for (int32_t q0 = 0; q0 < nq && rc == PRB_OK;) {
+    const auto tw0 = std::chrono::steady_clock::now();
     int32_t q1 = q0;
     double acc = 0;
-    while (q1 < qb->nq && (q1 == q0 || acc + qpairs[q1] <= budget)) acc += qpairs[q1++];
-    rc = search_range(ctx, qb, db, page, *opts, last_stage, cands, qstart[q0], qstart[q1], hs);
+    cands.clear();
+    for (;;) { // queries [q0, q1) of this sub-batch: as many as fit the pair budget
+      if (q1 >= nq) break;
+      wait_for(q1);
+      if (q1 > q0 && acc + qpairs[q1] > budget) break;
+      acc += qpairs[q1];
+      cands.insert(cands.end(), per_q[q1].begin(), per_q[q1].end());
+      std::vector<SeedCandidate>().swap(per_q[q1]);
+      q1++;
+    }
+    wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+    rc = search_range(ctx, qb, db, page, *opts, last_stage, cands, 0, cands.size(), hs);
     q0 = q1;
   }
+  producer.join();
+  ctx->timers["host_dfs"].ms += dfs_ms;       // wall time of the background DFS
+  ctx->timers["host_dfs"].launches++;
+  ctx->timers["host_dfs_wait"].ms += wait_ms; // what the GPU pipeline actually waited for it
+  ctx->timers["host_dfs_wait"].launches++;
   if (rc != PRB_OK) {
     delete hs;
     return rc;

@@ -231,6 +231,14 @@ __global__ __launch_bounds__(kBlock) void k_gather_hits(HitSoA s, const uint32_t
   d.e_tot[i] = s.e_tot[j];
 }
 
+// keep[i] = 1 unless E_i > threshold.  A hit above the threshold is flagged by CheckRedundancy
+// the moment the sweep reaches it and never flags anything else (as the contained hit of an
+// earlier scan it loses: E_a <= threshold < E_b), so it can be dropped BEFORE the sort.
+__global__ __launch_bounds__(kBlock) void k_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) keep[i] = !(e_tot[i] > thr);
+}
+
 // first[i] = 1 for the first hit of every query in a (query-sorted) list
 __global__ __launch_bounds__(kBlock) void k_mark_first(const int32_t *query, int64_t n, uint8_t *first) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -379,6 +387,11 @@ hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_gather_hits, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_flag_not_above, grid_for(n), dim3(kBlock), 0, s, e_tot, n, thr, keep);
   return hipGetLastError();
 }
 hipError_t launch_mark_first(const int32_t *query, int64_t n, uint8_t *first, hipStream_t s) {

@@ -98,6 +98,7 @@ hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, u
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
+hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s);
 hipError_t launch_mark_first(const int32_t *query, int64_t n, uint8_t *first, hipStream_t s);
 // ---- redundancy filter on a sorted list ----
 // state: 0 unknown, 1 active, 2 inactive; keep[i] = 1 for survivors
