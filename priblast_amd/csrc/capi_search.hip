@@ -41,11 +41,11 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp;
+      scanTmp, tierOf, tierFin, listA, listB;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB})
       b->release();
   }
 };
@@ -722,11 +722,16 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = w.hitsC.ensure(hits_bytes(nung)))) return rc;
   HitSoA G = carve_hits(w.hitsC, nung);
   if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4)) ||
-      (rc = w.ntrace.ensure((size_t)nung * 4)))
+      (rc = w.ntrace.ensure((size_t)nung * 4)) || (rc = w.tierOf.ensure((size_t)nung)) ||
+      (rc = w.listA.ensure((size_t)nung * 4)) || (rc = w.listB.ensure((size_t)nung * 4)) || (rc = w.count.ensure(16)))
     return rc;
-  int64_t hs_slow = 0;
-  const bool force_wave = getenv("PRB_FORCE_WAVE_GAPPED") != nullptr; // testing: bypass the LDS kernels
-  const bool skip_tier1 = getenv("PRB_GAPPED_SKIP_TIER1") != nullptr; // testing: everything through tier 2
+  // The cascade of kernels a hit goes through until one has the capacity for it: LDS tier 0
+  // (8 lanes per hit), LDS tier 1 (16 lanes), then the wave-per-hit kernel with HBM scratch.
+  // The environment switches exist for the tests: they force the rarely taken kernels.
+  std::vector<int> cascade{0, 1, 3};
+  if (getenv("PRB_FORCE_WAVE_GAPPED")) cascade = {3};
+  else if (getenv("PRB_GAPPED_SKIP_TIER1")) cascade = {2, 3}; // the large-capacity LDS instantiation
+  else if (getenv("PRB_GAPPED_SKIP_TIER0")) cascade = {1, 3};
   auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
     gs.cap_diag = cap_diag;
     gs.cap_rec = cap_rec;
@@ -738,35 +743,49 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     gs.base = w.gapScratch.as<uint8_t>();
     return r;
   };
-  // Slow path: wave-per-hit kernel with its state in HBM scratch, for the hit list `list`
-  // (indices into U), growing the scratch 4x for hits that still overflow.  mode 0 writes G; modes 1/2 use
-  // cnt_dev / off_dev (indexed by position in `list`).
-  auto run_slow = [&](int mode, std::vector<uint32_t> list, const int64_t *off_dev) -> int {
+  // next = the entries of the work list `cur` (nullptr: 0..m-1) whose overflow flag is set
+  auto select_overflow = [&](const uint32_t *cur, int64_t m, uint32_t *next, int64_t *mout) -> int {
+    size_t tmp = 0, cnt = 0;
+    const uint8_t *flags = w.overflow.as<uint8_t>();
+    if (cur) {
+      PRB_HIP(rocprim::select(nullptr, tmp, cur, flags, next, w.count.as<size_t>(), (size_t)m, ctx->stream));
+      if ((rc = w.scanTmp.ensure(tmp))) return rc;
+      PRB_HIP(rocprim::select(w.scanTmp.p, tmp, cur, flags, next, w.count.as<size_t>(), (size_t)m, ctx->stream));
+    } else {
+      rocprim::counting_iterator<uint32_t> iota(0);
+      PRB_HIP(rocprim::select(nullptr, tmp, iota, flags, next, w.count.as<size_t>(), (size_t)m, ctx->stream));
+      if ((rc = w.scanTmp.ensure(tmp))) return rc;
+      PRB_HIP(rocprim::select(w.scanTmp.p, tmp, iota, flags, next, w.count.as<size_t>(), (size_t)m, ctx->stream));
+    }
+    PRB_HIP(hipMemcpyAsync(&cnt, w.count.p, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    *mout = (int64_t)cnt;
+    return PRB_OK;
+  };
+  // Wave-per-hit kernel with its state in HBM scratch, for the device list `cur` (indices into U;
+  // nullptr = all) of m hits.  mode 0 writes G and retries hits that still overflow with a 4x
+  // larger scratch; mode 2 writes base pairs at off_dev (indexed by list position).
+  auto run_wave = [&](int mode, const uint32_t *cur, int64_t m, uint32_t *spare, const int64_t *off_dev) -> int {
     int cap_diag = 512, cap_rec = 2048;
     if (mode != 0) { // caps known to suffice for every hit seen so far
       cap_diag = std::max(512, ctx->max_gap_caps);
       cap_rec = cap_diag * 4;
     }
-    std::vector<uint8_t> ov;
-    while (!list.empty()) {
+    uint32_t *other = spare;
+    while (m > 0) {
       GapScratch gs;
-      const int64_t m = (int64_t)list.size();
       if ((rc = scratch_for(m, cap_diag, cap_rec, gs))) return rc;
-      if ((rc = w.subset2.ensure((size_t)m * 4))) return rc;
-      PRB_HIP(hipMemcpyAsync(w.subset2.p, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-      PRB_HIP(launch_gapped_wave(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, gs, mode,
-                                 mode == 0 ? w.overflow.as<uint8_t>() : nullptr, w.first.as<uint8_t>(),
+      PRB_HIP(launch_gapped_wave(U, G, m, cur, qb->view, pd, sc, eo, gs, mode, mode == 0 ? w.overflow.as<uint8_t>() : nullptr,
+                                 mode == 0 ? w.tierOf.as<uint8_t>() : nullptr, w.first.as<uint8_t>(),
                                  mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream));
-      ctx->timers["gapped_slow"].launches++;
       if (mode != 0) break;
-      ov.resize((size_t)m);
-      PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-      PRB_HIP(hipStreamSynchronize(ctx->stream));
-      std::vector<uint32_t> again;
-      for (int64_t i = 0; i < m; i++)
-        if (ov[i]) again.push_back(list[i]);
-      list.swap(again);
-      if (list.empty()) break;
+      int64_t again = 0;
+      if ((rc = select_overflow(cur, m, other, &again))) return rc;
+      uint32_t *done_list = const_cast<uint32_t *>(cur);
+      cur = other;
+      other = done_list ? done_list : (other == w.listA.as<uint32_t>() ? w.listB.as<uint32_t>() : w.listA.as<uint32_t>());
+      m = again;
+      if (m == 0) break;
       cap_diag *= 4;
       cap_rec *= 4;
       if (cap_diag > 32768) {
@@ -777,54 +796,32 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     }
     return PRB_OK;
   };
-  // extends every hit of U into G: LDS kernel tier 1, its overflows through tier 2, the rest
-  // through the wave kernel.  tier_of[x] remembers which one completed hit x.
-  std::vector<uint8_t> tier_of;
-  auto run_gapped = [&](int64_t n) -> int {
-    tier_of.assign((size_t)n, 3);
-    std::vector<uint32_t> list;
-    if (!force_wave) {
-      std::vector<uint8_t> ov((size_t)n, 1);
-      if (!skip_tier1) {
-        if ((rc = ctx->time_begin())) return rc;
-        PRB_HIP(launch_gapped_lds(U, G, n, nullptr, qb->view, pd, sc, eo, 0, 1, w.overflow.as<uint8_t>(),
+  static const char *const kTierTimer[4] = {"gapped", "gapped_t1", "gapped_t2", "gapped_slow"};
+  {
+    const uint32_t *cur = nullptr; // all of U
+    int64_t m = nung;
+    uint32_t *bufs[2] = {w.listA.as<uint32_t>(), w.listB.as<uint32_t>()};
+    int nb = 0;
+    for (size_t c = 0; c < cascade.size() && m > 0; c++) {
+      const int tier = cascade[c];
+      if ((rc = ctx->time_begin())) return rc;
+      if (tier == 3) {
+        hs->slow_hits += m;
+        ctx->slow_hits += m;
+        if ((rc = run_wave(0, cur, m, bufs[nb], nullptr))) return rc;
+        m = 0;
+      } else {
+        PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                   w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), nullptr, nullptr, ctx->stream));
-        if ((rc = ctx->time_end("gapped", 1))) return rc;
-        PRB_HIP(hipMemcpyAsync(ov.data(), w.overflow.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-        PRB_HIP(hipStreamSynchronize(ctx->stream));
+        int64_t rest = 0;
+        if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
+        cur = bufs[nb];
+        nb ^= 1;
+        m = rest;
       }
-      for (int64_t i = 0; i < n; i++) {
-        if (ov[i]) list.push_back((uint32_t)i);
-        else tier_of[i] = 1;
-      }
-      hs_slow += (int64_t)list.size();
-    } else {
-      for (int64_t i = 0; i < n; i++) list.push_back((uint32_t)i);
+      if ((rc = ctx->time_end(kTierTimer[tier], 1))) return rc;
     }
-    if (list.empty()) return PRB_OK;
-    if ((rc = ctx->time_begin())) return rc;
-    if (skip_tier1) { // testing: the large-capacity LDS instantiation, then the wave kernel for its overflows
-      const int64_t m = (int64_t)list.size();
-      if ((rc = w.subset2.ensure((size_t)m * 4))) return rc;
-      PRB_HIP(hipMemcpyAsync(w.subset2.p, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-      PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 0, 2, w.overflow.as<uint8_t>(),
-                                w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), nullptr, nullptr, ctx->stream));
-      std::vector<uint8_t> ov2((size_t)m);
-      PRB_HIP(hipMemcpyAsync(ov2.data(), w.overflow.p, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-      PRB_HIP(hipStreamSynchronize(ctx->stream));
-      std::vector<uint32_t> rest;
-      for (int64_t i = 0; i < m; i++) {
-        if (ov2[i]) rest.push_back(list[i]);
-        else tier_of[list[i]] = 2;
-      }
-      list.swap(rest);
-    }
-    if (!list.empty() && (rc = run_slow(0, std::move(list), nullptr))) return rc;
-    return ctx->time_end("gapped_slow", 0);
-  };
-  if ((rc = run_gapped(nung))) return rc;
-  hs->slow_hits += hs_slow;
-  ctx->slow_hits += hs_slow;
+  }
 
   // ---- final sort + filter (hits above the -g threshold dropped first) ----
   HitSoA G2 = carve_hits(w.hitsB, nung);
@@ -855,7 +852,9 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
 
   // ---- traceback of the survivors: re-run their extension, count then write base pairs ----
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = w.bpCount.ensure((size_t)(nfin + 1) * 4)) || (rc = w.bpOff.ensure((size_t)(nfin + 1) * 8))) return rc;
+  if ((rc = w.bpCount.ensure((size_t)(nfin + 1) * 4)) || (rc = w.bpOff.ensure((size_t)(nfin + 1) * 8)) ||
+      (rc = w.tierFin.ensure((size_t)nfin)))
+    return rc;
   {
     std::vector<uint32_t> pre((size_t)nfin); // index of each final hit's pre-gapped state in U
     PRB_HIP(hipMemcpyAsync(pre.data(), w.subset.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -863,48 +862,55 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
                             w.bpCount.as<int32_t>(), ctx->stream));
     std::vector<int32_t> cnt((size_t)nfin);
     PRB_HIP(hipMemcpyAsync(cnt.data(), w.bpCount.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // which kernel of the cascade completed each final hit: the same one traces it
+    std::vector<uint8_t> tier_fin((size_t)nfin);
+    PRB_HIP(launch_gather_u8(w.tierOf.as<uint8_t>(), w.subset.as<uint32_t>(), w.tierFin.as<uint8_t>(), nfin, ctx->stream));
+    PRB_HIP(hipMemcpyAsync(tier_fin.data(), w.tierFin.p, (size_t)nfin, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
-    // final hits whose extension needs tier 2 / the wave kernel (beyond the tier-1 capacities)
-    std::vector<uint32_t> pos2, list2, pos3, list3;
-    for (int64_t i = 0; i < nfin; i++) {
-      const uint8_t t = tier_of[pre[i]];
-      if (t == 2) {
-        pos2.push_back((uint32_t)i);
-        list2.push_back(pre[i]);
-      } else if (t == 3) {
-        pos3.push_back((uint32_t)i);
-        list3.push_back(pre[i]);
-      }
-    }
     std::vector<int64_t> off((size_t)nfin + 1, 0);
     for (int64_t i = 0; i < nfin; i++) off[i + 1] = off[i] + cnt[i];
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
     PRB_HIP(hipMemcpyAsync(w.bpOff.p, off.data(), (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (!force_wave && !skip_tier1)
-      PRB_HIP(launch_gapped_lds(U, G, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, eo, 2, 1, nullptr,
-                                w.first.as<uint8_t>(), nullptr, w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
-    if (!list2.empty() || !list3.empty()) {
-      if ((rc = ctx->time_end("traceback", 1))) return rc;
-      if ((rc = ctx->time_begin())) return rc;
-      if (!list2.empty()) {
-        std::vector<int64_t> o2(list2.size());
-        for (size_t k = 0; k < o2.size(); k++) o2[k] = off[pos2[k]];
-        if ((rc = w.bpOff2.ensure(o2.size() * 8)) || (rc = w.subset2.ensure(list2.size() * 4))) return rc;
-        PRB_HIP(hipMemcpyAsync(w.bpOff2.p, o2.data(), o2.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        PRB_HIP(hipMemcpyAsync(w.subset2.p, list2.data(), list2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        PRB_HIP(launch_gapped_lds(U, G, (int64_t)list2.size(), w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, 2, nullptr,
-                                  w.first.as<uint8_t>(), nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
-        PRB_HIP(hipStreamSynchronize(ctx->stream)); // o2 / list2 are reused below
+    std::vector<uint32_t> tlist[4];
+    std::vector<int64_t> toff[4];
+    for (int64_t i = 0; i < nfin; i++) {
+      const int t = tier_fin[i] & 3;
+      tlist[t].push_back(pre[i]);
+      toff[t].push_back(off[i]);
+    }
+    // the first tier of the cascade takes the bulk: it runs over all final hits with the offsets
+    // in place (hits it cannot hold are skipped); the others get their own lists
+    const int first_tier = cascade[0];
+    bool timed_main = false;
+    for (int t = 0; t < 4; t++) {
+      if (tlist[t].empty()) continue;
+      const int64_t m = (int64_t)tlist[t].size();
+      if (t != first_tier && !timed_main) {
+        if ((rc = ctx->time_end("traceback", 1))) return rc;
+        if ((rc = ctx->time_begin())) return rc;
+        timed_main = true;
       }
-      if (!list3.empty()) {
-        std::vector<int64_t> o3(list3.size());
-        for (size_t k = 0; k < o3.size(); k++) o3[k] = off[pos3[k]];
-        if ((rc = w.bpOff2.ensure(o3.size() * 8))) return rc;
-        PRB_HIP(hipMemcpyAsync(w.bpOff2.p, o3.data(), o3.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        if ((rc = run_slow(2, list3, w.bpOff2.as<int64_t>()))) return rc;
-        PRB_HIP(hipStreamSynchronize(ctx->stream));
+      const uint32_t *list_dev = w.subset.as<uint32_t>();
+      const int64_t *off_dev = w.bpOff.as<int64_t>();
+      int64_t n_launch = nfin;
+      if (t != first_tier) {
+        if ((rc = w.bpOff2.ensure((size_t)m * 8)) || (rc = w.subset2.ensure((size_t)m * 4))) return rc;
+        PRB_HIP(hipMemcpyAsync(w.bpOff2.p, toff[t].data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+        PRB_HIP(hipMemcpyAsync(w.subset2.p, tlist[t].data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
+        list_dev = w.subset2.as<uint32_t>();
+        off_dev = w.bpOff2.as<int64_t>();
+        n_launch = m;
       }
+      if (t == 3) {
+        if ((rc = run_wave(2, list_dev, n_launch, nullptr, off_dev))) return rc;
+      } else {
+        PRB_HIP(launch_gapped_lds(U, G, n_launch, list_dev, qb->view, pd, sc, eo, 2, t, nullptr, nullptr, w.first.as<uint8_t>(),
+                                  nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream));
+      }
+      if (t != first_tier) PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging vectors are reused
+    }
+    if (timed_main) {
       if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
       if ((rc = ctx->time_begin())) return rc;
     }

@@ -27,16 +27,51 @@
 
 namespace prb {
 
+// Developer-only cycle breakdown of the gapped kernel (make PROF=1 builds libpriblast_hip_prof.so;
+// tools/gapped_profile.py reads it).  Not part of the product build.
+#ifdef PRB_GAP_PROFILE
+__device__ unsigned long long g_gap_prof[8 * 16]; // [tier * 2 + (mode != 0)][region]
+struct GapProf {
+  unsigned long long last, acc[16];
+  __device__ __forceinline__ void start() {
+    for (int i = 0; i < 16; i++) acc[i] = 0;
+    last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int r) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[r] += t - last;
+    last = t;
+  }
+  __device__ __forceinline__ void count(int r) { acc[r] += 1; }
+  __device__ __forceinline__ void flush(int kind) {
+    if ((threadIdx.x & 63) == 0)
+      for (int i = 0; i < 16; i++) atomicAdd(&g_gap_prof[kind * 16 + i], acc[i]);
+  }
+};
+#define GP_MARK(r) prof.mark(r)
+#define GP_COUNT(r) prof.count(r)
+#else
+struct GapProf {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void flush(int) {}
+};
+#define GP_MARK(r)
+#define GP_COUNT(r)
+#endif
+
 namespace {
 
-constexpr int kLdsGroup = 16;
-constexpr int kStage = 16; // extension lengths whose accessibility terms are staged at a time
-// LDS tiers: (anti-diagonals, filled cells) per direction, groups (= hits) per workgroup
-struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads per CU
-  static constexpr int kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3;
+constexpr int kStageHbm = 16; // extension lengths whose accessibility terms are staged at a time (HBM form)
+// LDS tiers: lanes per hit, (anti-diagonals, filled cells) per direction, groups (= hits) per
+// workgroup, staged extension lengths (<= lanes per hit)
+struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
+  static constexpr int kG = 8, kCapD = 32, kCapR = 56, kGroups = 32, kStage = 8, kWavesPerSimd = 3;
 };
-struct Tier2 { // 9.6 KB per hit, 2 workgroups of 128 threads per CU
-  static constexpr int kCapD = 128, kCapR = 448, kGroups = 8, kWavesPerSimd = 1;
+struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
+  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kStage = 16, kWavesPerSimd = 3;
+};
+struct Tier2 { // 9.6 KB per hit, 2 workgroups of 128 threads per CU (testing only)
+  static constexpr int kG = 16, kCapD = 128, kCapR = 448, kGroups = 8, kStage = 16, kWavesPerSimd = 1;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -62,13 +97,13 @@ struct Rec64 {
   static __device__ __forceinline__ int pred(word v) { return (int)(v >> 40); }
   static __device__ __forceinline__ int type(word v) { return (int)((v >> 32) & 0xF); }
 };
-static_assert(Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127, "Rec32 field widths");
+static_assert(Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127 && Tier0::kStage <= Tier0::kG, "Rec32 field widths");
 
 template <class T, class Rec> struct LdsState {
   double eq[T::kCapD], ed[T::kCapD];
   double hyb[T::kCapR];
   typename Rec::word info[T::kCapR];
-  float stage[6][kStage];       // accessibility terms of the next kStage extension lengths
+  float stage[6][T::kStage];    // accessibility terms of the next kStage extension lengths
   uint8_t ptab[3][T::kCapD + 16];
   uint8_t qb[T::kCapD + 16], db[T::kCapD + 16]; // bases along the extension, 0 = end of sequence / masked
 };
@@ -86,6 +121,7 @@ template <class T, class Rec> struct LdsStore {
   __device__ __forceinline__ uint8_t &qb(int t) const { return s.qb[t]; }
   __device__ __forceinline__ uint8_t &db(int t) const { return s.db[t]; }
   __device__ __forceinline__ float &stage(int k, int t) const { return s.stage[k][t]; }
+  __device__ __forceinline__ constexpr int nstage() const { return T::kStage; }
 };
 struct HbmStore { // one block of the scratch per group
   using R = Rec64;
@@ -104,7 +140,8 @@ struct HbmStore { // one block of the scratch per group
   __device__ __forceinline__ int ptab_len() const { return capd + 16; }
   __device__ __forceinline__ uint8_t &qb(int t) const { return qb_[t]; }
   __device__ __forceinline__ uint8_t &db(int t) const { return db_[t]; }
-  __device__ __forceinline__ float &stage(int k, int t) const { return stage_[k * kStage + t]; }
+  __device__ __forceinline__ float &stage(int k, int t) const { return stage_[k * kStageHbm + t]; }
+  __device__ __forceinline__ constexpr int nstage() const { return kStageHbm; }
 };
 
 // State traffic inside a group is produced and consumed by lanes of ONE wavefront; its
@@ -135,9 +172,10 @@ template <int G, bool kLds, class Store>
 __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, HitState &h, int flag, const uint8_t *qs,
                                       int qn, const float *qacc, const float *qcond, const uint8_t *ds, int64_t dn,
                                       const float *dacc, const float *dcond, const Store &S, int gl /* lane in group */,
-                                      int gbase /* first lane of the group in its wavefront */) {
+                                      int gbase /* first lane of the group in its wavefront */, GapProf &prof) {
   using R = typename Store::R;
   const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
+  const int kStage = S.nstage();
   double min_e = h.e_tot;
   const double first_a = h.e_acc;
   double min_a = first_a;
@@ -189,6 +227,7 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
   }
   group_sync<kLds>();
   int nrec = 1, lo = 0;
+  GP_MARK(0);
   double acc_prev = 0; // lane 0: eq[length-2]; lane 1 (or 0 when G == 1): ed[length-2]
 
   for (;;) {
@@ -257,6 +296,8 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
         }
       }
     }
+    GP_MARK(1);
+    GP_COUNT(10);
     const int cur = length % 3, d2 = (length + 1) % 3; // d2 = (length - 2) mod 3
     // recycle the row of anti-diagonal length-3 for this one
     for (int t = gl; t <= length; t += G) S.ptab(cur, t) = 0;
@@ -269,6 +310,7 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
         else break;
       }
     }
+    GP_MARK(2);
     const int dstart = nrec;
     const int i_lo = length - max_d > 1 ? length - max_d : 1;
     const int i_hi = max_q < length - 1 ? max_q : length - 1;
@@ -295,7 +337,10 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
       }
       unsigned long long vmask = __ballot(type1 != 0);
       if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
+      GP_MARK(3);
+      GP_COUNT(11);
       while (vmask) { // filled cells of this chunk, ascending i
+        GP_COUNT(12);
         const int b = __builtin_ctzll(vmask);
         vmask &= vmask - 1;
         const int ci = i0 + b, cj = length - ci;
@@ -304,6 +349,7 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
         double bte = 1000000.0; // INF
         int bk = lo;
         for (int k0 = lo; k0 < dstart; k0 += G) {
+          GP_COUNT(13);
           const int k = k0 + gl;
           if (k < dstart) {
             const auto v = S.info(k);
@@ -326,6 +372,7 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
             }
           }
         }
+        GP_MARK(4);
 #pragma unroll
         for (int m = G / 2; m >= 1; m >>= 1) { // (energy, index) minimum over the group
           const double ote = __shfl_xor(bte, m);
@@ -335,6 +382,7 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
             bk = ok;
           }
         }
+        GP_MARK(5);
         if (nrec >= S.cap_r()) {
           overflow = true;
           break;
@@ -362,13 +410,16 @@ __device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, H
           min_db_len = db_length + cj;
         }
         nrec++;
+        GP_MARK(6);
       }
       group_sync<kLds>();
+      GP_MARK(3);
     }
     if (overflow) break;
     if (length - min_length >= drop) break;
     if (!q_open && !d_open) break;
   }
+  GP_MARK(7);
   DirResult r;
   r.overflow = overflow;
   r.best = (q_length - min_q_len != 0 && db_length - min_db_len != 0) ? best : 0;
@@ -393,7 +444,9 @@ struct GapArgs {
   PageDev pg;
   SearchConst sc;
   ExtOpts o;
-  uint8_t *overflow;
+  uint8_t *overflow;  // mode 0: overflow[w] = 1 if the capacities of this kernel did not suffice
+  uint8_t *tier_out;  // mode 0: tier_out[x] = tier_id when hit x was completed here
+  int tier_id;
   const uint8_t *first_flag;
   int32_t *bp_count; // mode 0: traced pairs (left + right) of hit x; k_bp_count: total pairs of list entry w
   const int64_t *bp_off;
@@ -405,7 +458,7 @@ struct GapArgs {
 // alignment at bp_off[w] (the extension is recomputed: only the ~3 % of hits that survive the
 // final filter are ever traced).
 template <int kMode, int G, bool kLds, class Store>
-__device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, int gbase) {
+__device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, int gbase, GapProf &prof) {
   using R = typename Store::R;
   const SearchConst &sc = a.sc;
   const int64_t x = a.subset ? (int64_t)a.subset[w] : w;
@@ -440,7 +493,9 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
   for (int flag = 0; flag < 2 && !ovf; flag++) {
     const int q_start = flag == 0 ? h.q_sp : h.q_sp + h.q_len - 1;
     const int64_t db_start = flag == 0 ? (int64_t)h.db_sp : (int64_t)h.db_sp + h.db_len - 1;
-    const DirResult r = extend_dir_group<G, kLds>(sc, a.o, h, flag, qs, qn, qacc, qcond, ds, a.pg.nchars, dacc, dcond, S, gl, gbase);
+    GP_MARK(8);
+    const DirResult r = extend_dir_group<G, kLds>(sc, a.o, h, flag, qs, qn, qacc, qcond, ds, a.pg.nchars, dacc, dcond, S, gl,
+                                                  gbase, prof);
     ovf = r.overflow;
     if (!ovf) {
       // traceback (:300-308, :409-424): from the arg-min cell through the predecessors
@@ -469,11 +524,13 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
       }
     }
     group_sync<kLds>();
+    GP_MARK(7);
   }
   if (gl != 0) return;
   if (kMode == 0) {
     a.overflow[w] = ovf ? 1 : 0;
     if (!ovf) {
+      a.tier_out[x] = (uint8_t)a.tier_id;
       a.bp_count[x] = nleft + nright;
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
       const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, qn, ds, a.pg.nchars);
@@ -524,15 +581,21 @@ __global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const ui
 }
 
 template <int kMode, class T, class Rec>
-__global__ __launch_bounds__(kLdsGroup *T::kGroups, T::kWavesPerSimd) void k_gapped_lds(GapArgs a) {
+__global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_lds(GapArgs a) {
   __shared__ LdsState<T, Rec> lds[T::kGroups];
+  constexpr int kLdsGroup = T::kG;
   const int gl = threadIdx.x & (kLdsGroup - 1);
   const int gbase = (threadIdx.x & 63) & ~(kLdsGroup - 1);
   const int gid = threadIdx.x / kLdsGroup;
   const LdsStore<T, Rec> S{lds[gid]};
   const int64_t ngroups = (int64_t)gridDim.x * T::kGroups;
-  for (int64_t w = (int64_t)blockIdx.x * T::kGroups + gid; w < a.n; w += ngroups)
-    gapped_one<kMode, kLdsGroup, true>(a, w, S, gl, gbase);
+  GapProf prof;
+  prof.start();
+  for (int64_t w = (int64_t)blockIdx.x * T::kGroups + gid; w < a.n; w += ngroups) {
+    gapped_one<kMode, kLdsGroup, true>(a, w, S, gl, gbase, prof);
+    GP_MARK(9);
+  }
+  prof.flush(a.tier_id * 2 + (kMode != 0));
 }
 
 template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs a, GapScratch scratch) {
@@ -546,45 +609,64 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
   S.hyb_ = S.ed_ + S.capd;
   S.info_ = reinterpret_cast<uint64_t *>(S.hyb_ + S.capr);
   S.stage_ = reinterpret_cast<float *>(S.info_ + S.capr);
-  S.ptab_ = reinterpret_cast<uint8_t *>(S.stage_ + 6 * kStage);
+  S.ptab_ = reinterpret_cast<uint8_t *>(S.stage_ + 6 * kStageHbm);
   S.qb_ = S.ptab_ + 3 * ((size_t)S.capd + 16);
   S.db_ = S.qb_ + S.capd + 16;
-  for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) gapped_one<kMode, 64, false>(a, w, S, gl, 0);
+  GapProf prof;
+  prof.start();
+  for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) {
+    gapped_one<kMode, 64, false>(a, w, S, gl, 0, prof);
+    GP_MARK(9);
+  }
+  prof.flush(3 * 2 + (kMode != 0));
 }
 
 } // namespace
 
+#ifdef PRB_GAP_PROFILE
+extern "C" int prb_debug_gap_profile(unsigned long long *out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gap_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[128] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gap_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
-  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 6 * kStage * 4 + 5 * ((size_t)cap_diag + 16);
+  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 6 * kStageHbm * 4 + 5 * ((size_t)cap_diag + 16);
   return (b + 255) & ~(size_t)255;
 }
 
+namespace {
+template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode, hipStream_t s) {
+  const int64_t want = (a.n + T::kGroups - 1) / T::kGroups;
+  const dim3 grid((unsigned)std::min<int64_t>(want, 256 * 4 * 8)), blk(T::kG * T::kGroups);
+  if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec>), grid, blk, 0, s, a);
+  return hipGetLastError();
+}
+} // namespace
+
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
-                             const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off, int32_t *bp_out,
-                             hipStream_t s) {
+                             uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
+                             int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, first_flag, bp_count, bp_off, bp_out};
-  if (tier == 1) {
-    const int64_t want = (n + Tier1::kGroups - 1) / Tier1::kGroups;
-    const dim3 grid((unsigned)std::min<int64_t>(want, 256 * 4 * 8)), blk(kLdsGroup * Tier1::kGroups);
-    if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, Tier1, Rec32>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_gapped_lds<2, Tier1, Rec32>), grid, blk, 0, s, a);
-  } else {
-    const int64_t want = (n + Tier2::kGroups - 1) / Tier2::kGroups;
-    const dim3 grid((unsigned)std::min<int64_t>(want, 256 * 2 * 8)), blk(kLdsGroup * Tier2::kGroups);
-    if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, Tier2, Rec64>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_gapped_lds<2, Tier2, Rec64>), grid, blk, 0, s, a);
-  }
-  return hipGetLastError();
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, bp_off, bp_out};
+  if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
+  if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
+  return launch_tier<Tier2, Rec64>(a, mode, s);
 }
 
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
-                              uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
-                              int32_t *bp_out, hipStream_t s) {
+                              uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
+                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, first_flag, bp_count, bp_off, bp_out};
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, 3, first_flag, bp_count, bp_off, bp_out};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
   else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);

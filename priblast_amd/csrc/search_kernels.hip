@@ -384,6 +384,11 @@ hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
   hipLaunchKernelGGL(k_gather<uint32_t>, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
   return hipGetLastError();
 }
+hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather<uint8_t>, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
+  return hipGetLastError();
+}
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_gather_hits, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);

@@ -97,6 +97,7 @@ hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, u
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s);
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t *dst, int64_t n, hipStream_t s);
+hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
 hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s);
 hipError_t launch_mark_first(const int32_t *query, int64_t n, uint8_t *first, hipStream_t s);
@@ -119,19 +120,20 @@ size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
 // overflow[i] = 1 if the state capacity was too small, bp_count[x] = pairs traced back by the
 // two extensions of hit x; mode 2: write the base pairs of list entry i at bp_off[i] (hits
 // beyond the capacity are skipped).  launch_bp_count: total pairs per list entry.
-// launch_gapped_lds: 16 lanes per hit, state in LDS (fixed capacities; tier 1 small, tier 2 large).
+// launch_gapped_lds: a group of lanes per hit, state in LDS with fixed capacities: tier 0 = 8 lanes,
+// 32 anti-diagonals; tier 1 = 16 lanes, 64 anti-diagonals; tier 2 = 16 lanes, 128 (testing only).
 // launch_gapped_wave: one wavefront per hit, state in the HBM scratch (`scratch.nthreads`
 // wavefronts, `bytes_per_thread` bytes each = gapped_wave_scratch_bytes(cap_diag, cap_rec)).
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
-                             const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off, int32_t *bp_out,
-                             hipStream_t s);
+                             uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
+                             int32_t *bp_out, hipStream_t s);
 hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                            const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s);
 hipError_t launch_bp_ends(const int64_t *bp_off, int64_t n, const int32_t *bp, int32_t *ends, hipStream_t s);
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
-                              uint8_t *overflow, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
-                              int32_t *bp_out, hipStream_t s);
+                              uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
+                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
 
 } // namespace prb

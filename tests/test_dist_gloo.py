@@ -1,7 +1,7 @@
 """world_size-2 test (gloo, CPU) of the multi-process plumbing used by bench.py for N > 1:
 disjoint query batches per rank and the variable-length final hit gather."""
 import os
-import socket
+import tempfile
 import sys
 
 import numpy as np
@@ -10,12 +10,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, store, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from priblast_amd import capi, dist as pdist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
     try:
         per_step = 5
         covered = []
@@ -42,13 +41,10 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_sharding_and_gather():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    store = os.path.join(tempfile.mkdtemp(prefix="prb_gloo_"), "rendezvous")
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctxm.Process(target=_worker, args=(r, 2, store, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
