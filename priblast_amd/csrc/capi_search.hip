@@ -41,11 +41,11 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin})
       b->release();
   }
 };
@@ -723,7 +723,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   HitSoA G = carve_hits(w.hitsC, nung);
   if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4)) ||
       (rc = w.ntrace.ensure((size_t)nung * 4)) || (rc = w.tierOf.ensure((size_t)nung)) ||
-      (rc = w.listA.ensure((size_t)nung * 4)) || (rc = w.listB.ensure((size_t)nung * 4)) || (rc = w.count.ensure(16)))
+      (rc = w.listA.ensure((size_t)nung * 4)) || (rc = w.listB.ensure((size_t)nung * 4)) || (rc = w.count.ensure(16)) ||
+      (rc = w.trace.ensure((size_t)nung * 2 * kTraceCap * sizeof(uint16_t))))
     return rc;
   // The cascade of kernels a hit goes through until one has the capacity for it: LDS tier 0
   // (8 lanes per hit), LDS tier 1 (16 lanes), then the wave-per-hit kernel with HBM scratch.
@@ -812,7 +813,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         m = 0;
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
-                                  w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), nullptr, nullptr, ctx->stream));
+                                  w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
+                                  ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
         cur = bufs[nb];
@@ -850,10 +852,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   const size_t base = hs->hits.size();
   if ((rc = download_hits(ctx, F, nfin, hs->hits))) return rc;
 
-  // ---- traceback of the survivors: re-run their extension, count then write base pairs ----
+  // ---- base pairs of the survivors: from the trace slots of the extension pass; the few hits
+  // the slots cannot describe (wave-kernel hits, chains longer than a slot) are extended again ----
   if ((rc = ctx->time_begin())) return rc;
   if ((rc = w.bpCount.ensure((size_t)(nfin + 1) * 4)) || (rc = w.bpOff.ensure((size_t)(nfin + 1) * 8)) ||
-      (rc = w.tierFin.ensure((size_t)nfin)))
+      (rc = w.tierFin.ensure((size_t)nfin)) || (rc = w.ntraceFin.ensure((size_t)nfin * 4)))
     return rc;
   {
     std::vector<uint32_t> pre((size_t)nfin); // index of each final hit's pre-gapped state in U
@@ -862,55 +865,56 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
                             w.bpCount.as<int32_t>(), ctx->stream));
     std::vector<int32_t> cnt((size_t)nfin);
     PRB_HIP(hipMemcpyAsync(cnt.data(), w.bpCount.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
-    // which kernel of the cascade completed each final hit: the same one traces it
+    // which kernel of the cascade completed each final hit, and its chain lengths
     std::vector<uint8_t> tier_fin((size_t)nfin);
+    std::vector<uint32_t> ntr((size_t)nfin);
     PRB_HIP(launch_gather_u8(w.tierOf.as<uint8_t>(), w.subset.as<uint32_t>(), w.tierFin.as<uint8_t>(), nfin, ctx->stream));
+    PRB_HIP(launch_gather_u32(w.ntrace.as<uint32_t>(), w.subset.as<uint32_t>(), w.ntraceFin.as<uint32_t>(), nfin, ctx->stream));
     PRB_HIP(hipMemcpyAsync(tier_fin.data(), w.tierFin.p, (size_t)nfin, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipMemcpyAsync(ntr.data(), w.ntraceFin.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> off((size_t)nfin + 1, 0);
     for (int64_t i = 0; i < nfin; i++) off[i + 1] = off[i] + cnt[i];
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
     PRB_HIP(hipMemcpyAsync(w.bpOff.p, off.data(), (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.first.as<uint8_t>(), w.ntrace.as<int32_t>(),
+                             w.tierOf.as<uint8_t>(), w.trace.as<uint16_t>(), w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(),
+                             ctx->stream));
     std::vector<uint32_t> tlist[4];
     std::vector<int64_t> toff[4];
+    const bool no_slots = getenv("PRB_TRACE_NO_SLOTS") != nullptr; // testing: re-extend every final hit as well
+    const char *cap_env = getenv("PRB_TRACE_SLOT_CAP");               // testing: pretend the slots are shorter
+    const int slot_cap = cap_env ? std::min(kTraceCap, atoi(cap_env)) : kTraceCap;
     for (int64_t i = 0; i < nfin; i++) {
       const int t = tier_fin[i] & 3;
-      tlist[t].push_back(pre[i]);
-      toff[t].push_back(off[i]);
+      if (no_slots || t == 3 || (int)(ntr[i] & 0xFFFF) > slot_cap || (int)(ntr[i] >> 16) > slot_cap) {
+        tlist[t].push_back(pre[i]);
+        toff[t].push_back(off[i]);
+      }
     }
-    // the first tier of the cascade takes the bulk: it runs over all final hits with the offsets
-    // in place (hits it cannot hold are skipped); the others get their own lists
-    const int first_tier = cascade[0];
-    bool timed_main = false;
+    bool any_rerun = false;
     for (int t = 0; t < 4; t++) {
       if (tlist[t].empty()) continue;
       const int64_t m = (int64_t)tlist[t].size();
-      if (t != first_tier && !timed_main) {
+      if (!any_rerun) {
         if ((rc = ctx->time_end("traceback", 1))) return rc;
         if ((rc = ctx->time_begin())) return rc;
-        timed_main = true;
+        any_rerun = true;
       }
-      const uint32_t *list_dev = w.subset.as<uint32_t>();
-      const int64_t *off_dev = w.bpOff.as<int64_t>();
-      int64_t n_launch = nfin;
-      if (t != first_tier) {
-        if ((rc = w.bpOff2.ensure((size_t)m * 8)) || (rc = w.subset2.ensure((size_t)m * 4))) return rc;
-        PRB_HIP(hipMemcpyAsync(w.bpOff2.p, toff[t].data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
-        PRB_HIP(hipMemcpyAsync(w.subset2.p, tlist[t].data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-        list_dev = w.subset2.as<uint32_t>();
-        off_dev = w.bpOff2.as<int64_t>();
-        n_launch = m;
-      }
+      if ((rc = w.bpOff2.ensure((size_t)m * 8)) || (rc = w.subset2.ensure((size_t)m * 4))) return rc;
+      PRB_HIP(hipMemcpyAsync(w.bpOff2.p, toff[t].data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+      PRB_HIP(hipMemcpyAsync(w.subset2.p, tlist[t].data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
       if (t == 3) {
-        if ((rc = run_wave(2, list_dev, n_launch, nullptr, off_dev))) return rc;
+        if ((rc = run_wave(2, w.subset2.as<uint32_t>(), m, nullptr, w.bpOff2.as<int64_t>()))) return rc;
       } else {
-        PRB_HIP(launch_gapped_lds(U, G, n_launch, list_dev, qb->view, pd, sc, eo, 2, t, nullptr, nullptr, w.first.as<uint8_t>(),
-                                  nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream));
+        PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,
+                                  w.first.as<uint8_t>(), nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
+                                  ctx->stream));
       }
-      if (t != first_tier) PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging vectors are reused
+      PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are reused by the next tier
     }
-    if (timed_main) {
+    if (any_rerun) {
       if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
       if ((rc = ctx->time_begin())) return rc;
     }

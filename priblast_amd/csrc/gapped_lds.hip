@@ -448,7 +448,8 @@ struct GapArgs {
   uint8_t *tier_out;  // mode 0: tier_out[x] = tier_id when hit x was completed here
   int tier_id;
   const uint8_t *first_flag;
-  int32_t *bp_count; // mode 0: traced pairs (left + right) of hit x; k_bp_count: total pairs of list entry w
+  int32_t *bp_count; // mode 0: traced pairs of hit x, left | right << 16
+  uint16_t *trace;   // mode 0 (LDS tiers): the first kTraceCap traced cells (i | j << 8) per direction of hit x
   const int64_t *bp_off;
   int32_t *bp_out;
 };
@@ -498,9 +499,16 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
                                                   gbase, prof);
     ovf = r.overflow;
     if (!ovf) {
-      // traceback (:300-308, :409-424): from the arg-min cell through the predecessors
+      // traceback (:300-308, :409-424): from the arg-min cell through the predecessors.  The
+      // extension pass leaves the chain in the hit's trace slot, so that the base pairs of the
+      // few hits that survive the final filter can be written without extending them again.
       int cnt = 0;
-      for (int k = r.best; k != 0; k = R::pred(S.info(k))) cnt++;
+      for (int k = r.best; k != 0; k = R::pred(S.info(k)), cnt++) {
+        if (kMode == 0 && kLds && gl == 0 && cnt < kTraceCap) {
+          const auto v = S.info(k);
+          a.trace[(x * 2 + flag) * kTraceCap + cnt] = (uint16_t)(R::i(v) | (R::j(v) << 8));
+        }
+      }
       if (flag == 0) nleft = cnt;
       else nright = cnt;
       if (kMode == 2 && gl == 0) {
@@ -531,7 +539,7 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
     a.overflow[w] = ovf ? 1 : 0;
     if (!ovf) {
       a.tier_out[x] = (uint8_t)a.tier_id;
-      a.bp_count[x] = nleft + nright;
+      a.bp_count[x] = nleft | (nright << 16);
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
       const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, qn, ds, a.pg.nchars);
       const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, qs, qn,
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const ui
   const int len = US(in.q_len[x]);
   int c = 0;
   for (int t = 0; t < len; t++) c += sc.bp_pair[(qs[t] - 1) * 5 + (ds[t] - 1)] != 0;
-  bp_count[w] = c + ntrace[x];
+  bp_count[w] = c + (ntrace[x] & 0xFFFF) + (int)((uint32_t)ntrace[x] >> 16);
 }
 
 template <int kMode, class T, class Rec>
@@ -652,10 +660,10 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
 
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
-                             uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
-                             int32_t *bp_out, hipStream_t s) {
+                             uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
+                             const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, bp_off, bp_out};
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, trace, bp_off, bp_out};
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
   return launch_tier<Tier2, Rec64>(a, mode, s);
@@ -666,10 +674,61 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
                               const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, 3, first_flag, bp_count, bp_off, bp_out};
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, 3, first_flag, bp_count, nullptr, bp_off, bp_out};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
   else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);
+  return hipGetLastError();
+}
+
+// Base pairs of final hit w from the trace slot its extension pass left (same layout as mode 2
+// of the gapped kernels writes).  Hits completed by the wave kernel (tier 3) or with a chain
+// longer than the slot are left to the mode-2 pass.
+__global__ __launch_bounds__(256) void k_bp_expand(HitSoA in, int64_t n, const uint32_t *__restrict__ subset, QBatchDev qb,
+                                                   PageDev pg, SearchConst sc, const uint8_t *__restrict__ first_flag,
+                                                   const int32_t *__restrict__ ntrace, const uint8_t *__restrict__ tier_of,
+                                                   const uint16_t *__restrict__ trace, const int64_t *__restrict__ bp_off,
+                                                   int32_t *bp_out) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  const int64_t x = subset[w];
+  const int nleft = ntrace[x] & 0xFFFF, nright = (int)((uint32_t)ntrace[x] >> 16);
+  if (tier_of[x] >= 3 || nleft > kTraceCap || nright > kTraceCap) return;
+  const int q_sp = in.q_sp[x], db_sp = in.db_sp[x], len = US(in.q_len[x]);
+  const uint8_t *qs = qb.enc + qb.off[in.query[x]] + q_sp;
+  const uint8_t *ds = pg.seqs + db_sp;
+  const bool unsorted = first_flag[x] != 0; // hit 0 of a query keeps the raw pair order
+  const int64_t out0 = bp_off[w];
+  int ndiag = 0;
+  const int64_t d0 = unsorted ? out0 : out0 + nleft;
+  for (int t = 0; t < len; t++)
+    if (sc.bp_pair[(qs[t] - 1) * 5 + (ds[t] - 1)] != 0) {
+      bp_out[2 * (d0 + ndiag)] = q_sp + t;
+      bp_out[2 * (d0 + ndiag) + 1] = db_sp + t;
+      ndiag++;
+    }
+  const uint16_t *sl = trace + x * 2 * kTraceCap;
+  for (int t = 0; t < nleft; t++) {
+    const int v = sl[t];
+    const int64_t pos = unsorted ? out0 + ndiag + t : out0 + t;
+    bp_out[2 * pos] = q_sp - (v & 0xFF);
+    bp_out[2 * pos + 1] = db_sp - (v >> 8);
+  }
+  const int q_end = q_sp + in.q_len[x] - 1, db_end = db_sp + in.db_len[x] - 1;
+  for (int t = 0; t < nright; t++) {
+    const int v = sl[kTraceCap + t];
+    const int64_t pos = unsorted ? out0 + ndiag + nleft + t : out0 + nleft + ndiag + (nright - 1 - t);
+    bp_out[2 * pos] = q_end + (v & 0xFF);
+    bp_out[2 * pos + 1] = db_end + (v >> 8);
+  }
+}
+
+hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
+                            const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
+                            const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bp_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, subset, qb, pg, sc, first_flag,
+                     ntrace, tier_of, trace, bp_off, bp_out);
   return hipGetLastError();
 }
 

@@ -126,8 +126,16 @@ size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
 // wavefronts, `bytes_per_thread` bytes each = gapped_wave_scratch_bytes(cap_diag, cap_rec)).
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
-                             uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, const int64_t *bp_off,
-                             int32_t *bp_out, hipStream_t s);
+                             uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
+                             const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
+// Trace slots: the extension pass (mode 0, LDS tiers) leaves the first kTraceCap cells (i | j << 8)
+// of each direction's traceback chain of hit x at trace[(2x + direction) * kTraceCap ...];
+// launch_bp_expand writes the base pairs of the final hits from them (hits of the wave kernel or
+// with longer chains are skipped: they are traced by a mode-2 pass).
+constexpr int kTraceCap = 32;
+hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
+                            const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
+                            const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
 hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                            const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s);
 hipError_t launch_bp_ends(const int64_t *bp_off, int64_t n, const int32_t *bp, int32_t *ends, hipStream_t s);
