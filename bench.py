@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
-STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_t1", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait")
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped", "gapped_t1", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait", "host_search_range", "host_download")
 
 
 def parse():
@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--queries", type=int, default=int(os.environ.get("BENCH_QUERIES", 512)), help="queries per GPU per step")
+    ap.add_argument("--queries", type=int, default=int(os.environ.get("BENCH_QUERIES", 2048)), help="queries per GPU per step")
     ap.add_argument("--db-seqs", type=int, default=int(os.environ.get("BENCH_DB_SEQS", 5000)))
     ap.add_argument("--length", type=int, default=int(os.environ.get("BENCH_LENGTH", 1000)))
     ap.add_argument("--cpu-queries", type=int, default=int(os.environ.get("BENCH_CPU_QUERIES", -1)),

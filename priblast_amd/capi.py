@@ -263,23 +263,44 @@ class QBatch:
         return lib().prb_qbatch_length_unmasked(self.h, q)
 
 
+class _HitSetOwner:
+    """Frees the prb_hitset when the last numpy view of it goes away."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        lib().prb_hitset_free(self.h)
+
+
+class _HitSetView:
+    """Array-interface window on memory of a hit set: numpy arrays made from it alias the
+    library's memory (no copy) and keep the owner alive through their .base chain."""
+
+    def __init__(self, owner, ptr, nbytes):
+        self._owner = owner
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+
 def search_page(ctx, qb, db, page, opts=None, last_stage=3):
-    """-> (hits: structured array HIT_DTYPE, bp: int32 [n,2], counts (seed, ungapped, final))."""
+    """-> (hits: structured array HIT_DTYPE, bp: int32 [n,2], counts (seed, ungapped, final)).
+    The arrays are views of the hit set (freed when the last of them goes away)."""
     o = opts or default_opts()
     h = ctypes.c_void_p()
     _check(lib().prb_search_page(ctx.h, qb.h, db.h, page, ctypes.byref(o), last_stage, ctypes.byref(h)))
-    try:
-        n = lib().prb_hitset_size(h)
-        hits = np.zeros(n, HIT_DTYPE)
-        if n:
-            ctypes.memmove(hits.ctypes.data, lib().prb_hitset_hits(h), n * HIT_DTYPE.itemsize)
-        cnt = c_i64()
-        p = lib().prb_hitset_basepairs(h, ctypes.byref(cnt))
-        bp = np.zeros((cnt.value, 2), np.int32)
-        if cnt.value:
-            ctypes.memmove(bp.ctypes.data, p, cnt.value * 8)
-        counts = (c_i64 * 3)()
-        lib().prb_hitset_counts(h, counts)
-        return hits, bp, tuple(counts)
-    finally:
+    counts = (c_i64 * 3)()
+    lib().prb_hitset_counts(h, counts)
+    n = lib().prb_hitset_size(h)
+    cnt = c_i64()
+    p = lib().prb_hitset_basepairs(h, ctypes.byref(cnt))
+    if n == 0:
         lib().prb_hitset_free(h)
+        return np.zeros(0, HIT_DTYPE), np.zeros((0, 2), np.int32), tuple(counts)
+
+    owner = _HitSetOwner(h)
+    hits = np.asarray(_HitSetView(owner, lib().prb_hitset_hits(h), n * HIT_DTYPE.itemsize)).view(HIT_DTYPE)
+    if cnt.value:
+        bp = np.asarray(_HitSetView(owner, p, cnt.value * 8)).view(np.int32).reshape(-1, 2)
+    else:
+        bp = np.zeros((0, 2), np.int32)
+    return hits, bp, tuple(counts)

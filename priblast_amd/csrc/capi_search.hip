@@ -37,16 +37,56 @@ struct PageMem {
   PageDev view{};
 };
 
+// pinned host staging buffer that only grows
+struct PinnedBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return PRB_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      set_error("out of pinned host memory allocating " + std::to_string(want) + " bytes");
+      return PRB_ERR_NOMEM;
+    }
+    cap = want;
+    return PRB_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 // buffers reused across prb_search_page calls
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed;
+  PinnedBuf pinned;
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed})
       b->release();
+    pinned.release();
+  }
+};
+
+// wall-clock timer for host-side pieces, reported next to the device stage timers (pseudo-stage names "host_*")
+struct HostTimer {
+  prb_ctx *ctx;
+  const char *name;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  HostTimer(prb_ctx *c, const char *n) : ctx(c), name(n) {}
+  ~HostTimer() {
+    auto &t = ctx->timers[name];
+    t.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    t.launches++;
   }
 };
 
@@ -588,33 +628,19 @@ static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n,
   return PRB_OK;
 }
 
-static int download_hits(prb_ctx *ctx, const HitSoA &h, int64_t n, std::vector<prb_hit> &out) {
+static int download_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, std::vector<prb_hit> &out) {
+  HostTimer ht(ctx, "host_download");
   const size_t base = out.size();
-  out.resize(base + (size_t)n);
   if (n == 0) return PRB_OK;
-  std::vector<int32_t> iv((size_t)n);
-  std::vector<double> dv((size_t)n);
-  auto geti = [&](const int32_t *src, int32_t prb_hit::*f) -> int {
-    PRB_HIP(hipMemcpy(iv.data(), src, (size_t)n * 4, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) out[base + i].*f = iv[i];
-    return PRB_OK;
-  };
-  auto getd = [&](const double *src, double prb_hit::*f) -> int {
-    PRB_HIP(hipMemcpy(dv.data(), src, (size_t)n * 8, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) out[base + i].*f = dv[i];
-    return PRB_OK;
-  };
-  PRB_HIP(hipStreamSynchronize(ctx->stream));
   int rc;
-  if ((rc = geti(h.q_sp, &prb_hit::q_sp)) || (rc = geti(h.db_sp, &prb_hit::db_sp)) || (rc = geti(h.q_len, &prb_hit::q_len)) ||
-      (rc = geti(h.db_len, &prb_hit::db_len)) || (rc = geti(h.db_id, &prb_hit::db_id)) ||
-      (rc = geti(h.db_id_start, &prb_hit::db_id_start)) || (rc = geti(h.query, &prb_hit::query)) ||
-      (rc = getd(h.e_acc, &prb_hit::e_acc)) || (rc = getd(h.e_hyb, &prb_hit::e_hyb)) || (rc = getd(h.e_tot, &prb_hit::e_tot)))
-    return rc;
-  for (int64_t i = 0; i < n; i++) {
-    out[base + i].bp_count = 0;
-    out[base + i].bp_offset = 0;
-  }
+  const size_t bytes = (size_t)n * sizeof(prb_hit);
+  if ((rc = w.packed.ensure(bytes)) || (rc = w.pinned.ensure(bytes))) return rc;
+  PRB_HIP(launch_pack_hits(h, n, w.packed.p, ctx->stream));
+  PRB_HIP(hipMemcpyAsync(w.pinned.p, w.packed.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (out.capacity() < base + (size_t)n) out.reserve(std::max(2 * out.capacity(), base + (size_t)n));
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  const prb_hit *src = static_cast<const prb_hit *>(w.pinned.p);
+  out.insert(out.end(), src, src + n);
   return PRB_OK;
 }
 
@@ -668,7 +694,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   HitSoA A = carve_hits(w.hitsA, nseed);
   PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.row_off.as<int64_t>(), A, ctx->stream));
   if ((rc = ctx->time_end("seed", 2))) return rc;
-  if (last_stage == 1) return download_hits(ctx, A, nseed, hs->hits);
+  if (last_stage == 1) return download_hits(ctx, w, A, nseed, hs->hits);
 
   // ---- ungapped extension, sort, redundancy filter ----
   if ((rc = ctx->time_begin())) return rc;
@@ -701,7 +727,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   PRB_HIP(launch_mark_first(U.query, nung, w.first.as<uint8_t>(), ctx->stream));
   if (last_stage == 2) {
     const size_t base = hs->hits.size();
-    if ((rc = download_hits(ctx, U, nung, hs->hits))) return rc;
+    if ((rc = download_hits(ctx, w, U, nung, hs->hits))) return rc;
     // GetBasePair (rna_interaction_search.cpp:371-385): complementary positions of the diagonal
     for (size_t i = base; i < hs->hits.size(); i++) {
       prb_hit &h = hs->hits[i];
@@ -814,7 +840,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                   w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
-                                  ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
         cur = bufs[nb];
@@ -850,7 +876,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset2.as<uint32_t>(), nfin, ctx->stream));
   PRB_HIP(launch_gather_u32(w.cidx.as<uint32_t>(), w.subset2.as<uint32_t>(), w.subset.as<uint32_t>(), nfin, ctx->stream));
   const size_t base = hs->hits.size();
-  if ((rc = download_hits(ctx, F, nfin, hs->hits))) return rc;
+  if ((rc = download_hits(ctx, w, F, nfin, hs->hits))) return rc;
 
   // ---- base pairs of the survivors: from the trace slots of the extension pass; the few hits
   // the slots cannot describe (wave-kernel hits, chains longer than a slot) are extended again ----
@@ -910,7 +936,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,
                                   w.first.as<uint8_t>(), nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
-                                  ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, ctx->stream));
       }
       PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are reused by the next tier
     }
@@ -1001,7 +1027,7 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   };
   auto *hs = new prb_hitset();
   const char *env = getenv("PRB_SEARCH_PAIRS");
-  const double budget = env ? atof(env) : 6.0e7;
+  const double budget = env ? atof(env) : 1.2e8;
   int rc = PRB_OK;
   std::vector<SeedCandidate> cands;
   double wait_ms = 0;
@@ -1020,7 +1046,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
       q1++;
     }
     wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
-    rc = search_range(ctx, qb, db, page, *opts, last_stage, cands, 0, cands.size(), hs);
+    {
+      HostTimer ht(ctx, "host_search_range");
+      rc = search_range(ctx, qb, db, page, *opts, last_stage, cands, 0, cands.size(), hs);
+    }
     q0 = q1;
   }
   producer.join();

@@ -61,17 +61,18 @@ struct GapProf {
 
 namespace {
 
+constexpr int kInitStage = 16; // extension lengths whose accessibility sums dir_init prepares
 constexpr int kStageHbm = 16; // extension lengths whose accessibility terms are staged at a time (HBM form)
 // LDS tiers: lanes per hit, (anti-diagonals, filled cells) per direction, groups (= hits) per
 // workgroup, staged extension lengths (<= lanes per hit)
 struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
-  static constexpr int kG = 8, kCapD = 32, kCapR = 56, kGroups = 32, kStage = 8, kWavesPerSimd = 3;
+  static constexpr int kG = 8, kCapD = 32, kCapR = 56, kGroups = 32, kStage = 8, kWavesPerSimd = 3, kWgPerCu = 3;
 };
 struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
-  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kStage = 16, kWavesPerSimd = 3;
+  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kStage = 16, kWavesPerSimd = 3, kWgPerCu = 3;
 };
 struct Tier2 { // 9.6 KB per hit, 2 workgroups of 128 threads per CU (testing only)
-  static constexpr int kG = 16, kCapD = 128, kCapR = 448, kGroups = 8, kStage = 16, kWavesPerSimd = 1;
+  static constexpr int kG = 16, kCapD = 128, kCapR = 448, kGroups = 8, kStage = 16, kWavesPerSimd = 1, kWgPerCu = 1;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -97,7 +98,7 @@ struct Rec64 {
   static __device__ __forceinline__ int pred(word v) { return (int)(v >> 40); }
   static __device__ __forceinline__ int type(word v) { return (int)((v >> 32) & 0xF); }
 };
-static_assert(Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127 && Tier0::kStage <= Tier0::kG, "Rec32 field widths");
+static_assert(Tier0::kCapR * 8 >= 6 * kInitStage * 4 && Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127 && Tier0::kStage <= Tier0::kG, "Rec32 field widths");
 
 template <class T, class Rec> struct LdsState {
   double eq[T::kCapD], ed[T::kCapD];
@@ -164,275 +165,329 @@ struct DirResult {
   int best; // cell index of the arg-min, 0 = nothing found
 };
 
-// GappedExtension::extension (gapped_extension.cpp:71-319) for one direction, by a group of G lanes.
-// Everything the anti-diagonal loop touches is staged on chip first: the bases along both
-// strands (so GetBPType / CheckHelixLength / LoopEnergy never go back to HBM), and the
-// accessibility terms kStage extension lengths at a time.
-template <int G, bool kLds, class Store>
-__device__ DirResult extend_dir_group(const SearchConst &sc, const ExtOpts &o, HitState &h, int flag, const uint8_t *qs,
-                                      int qn, const float *qacc, const float *qcond, const uint8_t *ds, int64_t dn,
-                                      const float *dacc, const float *dcond, const Store &S, int gl /* lane in group */,
-                                      int gbase /* first lane of the group in its wavefront */, GapProf &prof) {
-  using R = typename Store::R;
-  const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
-  const int kStage = S.nstage();
-  double min_e = h.e_tot;
-  const double first_a = h.e_acc;
-  double min_a = first_a;
-  int q_start;
-  int64_t db_start;
-  if (flag == 0) {
-    q_start = h.q_sp;
-    db_start = h.db_sp;
-  } else {
-    q_start = h.q_sp + h.q_len - 1;
-    db_start = (int64_t)h.db_sp + h.db_len - 1;
+// What a group knows about the hit it is extending.
+struct HitCtx {
+  int64_t x, out0;
+  const uint8_t *qs;
+  const float *qacc, *qcond, *dacc, *dcond;
+  HitState h;
+  int query, id, qn;
+  int diag_q, diag_d, diag_len, ndiag, nleft, nright;
+  bool unsorted, ovf;
+};
+
+// The scalars of one direction's recurrence (kept redundantly in every lane of the group).
+struct DirState {
+  double min_e, first_a, min_a;
+  double acc_prev; // lane 0: eq[length-2]; lane 1 (or 0 when G == 1): ed[length-2]
+  int64_t db_start, min_db_start;
+  int q_start, id_start, id_end, min_q_start, q_length, db_length, min_q_len, min_db_len, min_id_start;
+  int length, min_length, best, nrec, lo, tq0, td0;
+  bool overflow;
+};
+
+// Cumulative accessibility change of the extension (gapped_extension.cpp:156-212) for the nb
+// lengths from L0 on: the terms are fetched in parallel into the float scratch sf(term, t),
+// the sums are sequential (lane 0: query side -> eq[], lane 1: db side -> ed[]).
+template <int G, bool kLds, class Store, class SF>
+__device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, const Store &S, int gl, DirState &d, int L0,
+                                          int nb, SF sf) {
+  const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
+  for (int t = gl; t < nb; t += G) {
+    const int len = L0 + t;
+    if (len < d.tq0) {
+      if (flag == 0) {
+        const int p = d.q_start - len;
+        sf(0, t) = qacc[p];
+        sf(1, t) = qacc[p + 1];
+        sf(2, t) = qcond[p + delta];
+      } else {
+        sf(0, t) = qcond[d.q_start + len];
+      }
+    }
+    if (len < d.td0) {
+      if (flag == 0) {
+        sf(3, t) = dcond[d.id_end + len];
+      } else {
+        const int p = d.id_start - len;
+        sf(3, t) = dacc[p];
+        sf(4, t) = dacc[p + 1];
+        sf(5, t) = dcond[p + delta];
+      }
+    }
   }
-  const int id_start = h.id_start, id_end = id_start + h.db_len - 1;
-  int min_q_start = q_start;
-  int64_t min_db_start = db_start;
-  const int q_length = h.q_len, db_length = h.db_len;
-  int min_q_len = q_length, min_db_len = db_length, min_id_start = id_start;
-  int length = 0, min_length = 0, best = 0;
-  bool overflow = false;
+  group_sync<kLds>();
+  if (gl == 0) {
+    for (int k = 0; k < nb && L0 + k < d.tq0 && L0 + k <= S.cap_d(); k++) {
+      const int len = L0 + k;
+      double v;
+      if (flag == 0) {
+        if (len == 1) v = sf(0, k) - sf(1, k) + sf(2, k); // float arithmetic, as the reference
+        else v = d.acc_prev + sf(0, k) - sf(1, k) + sf(2, k);
+      } else {
+        if (len == 1) v = sf(0, k);
+        else v = d.acc_prev + sf(0, k);
+      }
+      d.acc_prev = v;
+      S.eq(len - 1) = v;
+    }
+  } else if (gl == 1) {
+    for (int k = 0; k < nb && L0 + k < d.td0 && L0 + k <= S.cap_d(); k++) {
+      const int len = L0 + k;
+      double v;
+      if (flag == 0) {
+        if (len == 1) v = sf(3, k);
+        else v = d.acc_prev + sf(3, k);
+      } else {
+        if (len == 1) v = sf(3, k) - sf(4, k) + sf(5, k);
+        else v = d.acc_prev + sf(3, k) - sf(4, k) + sf(5, k);
+      }
+      d.acc_prev = v;
+      S.ed(len - 1) = v;
+    }
+  }
+  group_sync<kLds>();
+}
+
+// GappedExtension::extension (gapped_extension.cpp:71-319) for one direction, by a group of G lanes,
+// in three pieces so that the groups of a wavefront can be at different points of different
+// hits: dir_init (state + everything the anti-diagonal loop touches staged on chip: the bases
+// along both strands, so GetBPType / CheckHelixLength / LoopEnergy never go back to HBM),
+// dir_step (one anti-diagonal; true when the direction is finished) and dir_finish.
+template <int G, bool kLds, class Store>
+__device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c, int flag, const uint8_t *ds, int64_t dn,
+                                         const Store &S, int gl, int delta, DirState &d) {
+  using R = typename Store::R;
+  const HitState &h = c.h;
+  const uint8_t *qs = c.qs;
+  const int qn = c.qn;
+  d.min_e = h.e_tot;
+  d.first_a = h.e_acc;
+  d.min_a = d.first_a;
+  if (flag == 0) {
+    d.q_start = h.q_sp;
+    d.db_start = h.db_sp;
+  } else {
+    d.q_start = h.q_sp + h.q_len - 1;
+    d.db_start = (int64_t)h.db_sp + h.db_len - 1;
+  }
+  d.id_start = h.id_start;
+  d.id_end = d.id_start + h.db_len - 1;
+  d.min_q_start = d.q_start;
+  d.min_db_start = d.db_start;
+  d.q_length = h.q_len;
+  d.db_length = h.db_len;
+  d.min_q_len = d.q_length;
+  d.min_db_len = d.db_length;
+  d.min_id_start = d.id_start;
+  d.length = 0;
+  d.min_length = 0;
+  d.best = 0;
+  d.overflow = false;
 
   // bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407);
   // the first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154)
   const int wn = S.ptab_len();
-  int tq0 = wn, td0 = wn;
+  d.tq0 = wn;
+  d.td0 = wn;
   for (int t = gl; t < wn; t += G) {
-    const int64_t qp = flag == 0 ? (int64_t)q_start - t : (int64_t)q_start + t;
-    const int64_t dp = flag == 0 ? db_start - t : db_start + t;
+    const int64_t qp = flag == 0 ? (int64_t)d.q_start - t : (int64_t)d.q_start + t;
+    const int64_t dp = flag == 0 ? d.db_start - t : d.db_start + t;
     const int qc = (qp >= 0 && qp < qn) ? get_char(qs, qp) : 0;
     const int dc = (dp >= 0 && dp < dn) ? get_char(ds, dp) : 0;
     S.qb(t) = (uint8_t)qc;
     S.db(t) = (uint8_t)dc;
-    if (t >= 1 && qc == 0 && t < tq0) tq0 = t;
-    if (t >= 1 && dc == 0 && t < td0) td0 = t;
+    if (t >= 1 && qc == 0 && t < d.tq0) d.tq0 = t;
+    if (t >= 1 && dc == 0 && t < d.td0) d.td0 = t;
   }
-  for (int t = gl; t < 3 * wn; t += G) S.ptab(0, t) = 0;
+  {
+    uint32_t *pz = reinterpret_cast<uint32_t *>(&S.ptab(0, 0)); // 3 rows of wn bytes, wn a multiple of 4
+    for (int t = gl; t < 3 * wn / 4; t += G) pz[t] = 0;
+  }
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) {
-    const int a = __shfl_xor(tq0, m), b = __shfl_xor(td0, m);
-    tq0 = a < tq0 ? a : tq0;
-    td0 = b < td0 ? b : td0;
+    const int ta = __shfl_xor(d.tq0, m), tb = __shfl_xor(d.td0, m);
+    d.tq0 = ta < d.tq0 ? ta : d.tq0;
+    d.td0 = tb < d.td0 ? tb : d.td0;
   }
   group_sync<kLds>();
+  // accessibility sums of the first kInitStage lengths (nearly every direction ends within them);
+  // the cell list is still empty, so its energies' storage serves as the float scratch
+  d.acc_prev = 0;
+  {
+    float *scratch = reinterpret_cast<float *>(&S.hyb(0));
+    stage_acc<G, kLds>(c, flag, delta, S, gl, d, 1, kInitStage, [&](int k, int t) -> float & { return scratch[k * kInitStage + t]; });
+  }
   int type0 = bp_type(sc, S.qb(0), S.db(0));
   if (flag == 0) type0 = rtype_of(type0);
   if (gl == 0) {
-    S.hyb(0) = min_e;
+    S.hyb(0) = d.min_e;
     S.info(0) = R::pack(0, 0, 0, type0, type0);
     S.ptab(0, 0) = (uint8_t)type0; // cell (0,0) lies on anti-diagonal 0
   }
   group_sync<kLds>();
-  int nrec = 1, lo = 0;
-  GP_MARK(0);
-  double acc_prev = 0; // lane 0: eq[length-2]; lane 1 (or 0 when G == 1): ed[length-2]
+  d.nrec = 1;
+  d.lo = 0;
+}
 
-  for (;;) {
-    length++;
-    if (length > S.cap_d()) {
-      overflow = true;
-      break;
+template <int G, bool kLds, class Store>
+__device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o, const HitCtx &c, int flag, const Store &S,
+                                         int gl /* lane in group */, int gbase /* first lane of the group in its wavefront */,
+                                         DirState &d, GapProf &prof) {
+  using R = typename Store::R;
+  const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
+  const int kStage = S.nstage();
+  const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
+  d.length++;
+  if (d.length > S.cap_d()) {
+    d.overflow = true;
+    return true;
+  }
+  // max_q_extension / max_db_extension as the reference has them after its checks at this d.length
+  const bool q_open = d.length < d.tq0, d_open = d.length < d.td0;
+  const int max_q = q_open ? 100000 : d.tq0 - 1, max_d = d_open ? 100000 : d.td0 - 1;
+  // cumulative accessibility change beyond the lengths dir_init staged, kStage lengths at a time
+  if ((d.length - 1) % kStage == 0 && d.length > kInitStage)
+    stage_acc<G, kLds>(c, flag, delta, S, gl, d, d.length, kStage, [&](int k, int t) -> float & { return S.stage(k, t); });
+  GP_MARK(1);
+  GP_COUNT(10);
+  const int cur = d.length % 3, d2 = (d.length + 1) % 3; // d2 = (d.length - 2) mod 3
+  // recycle the row of anti-diagonal d.length-3 for this one
+  for (int t = gl; t <= d.length; t += G) S.ptab(cur, t) = 0;
+  group_sync<kLds>();
+  // prune candidates with d.length - first - second - 2 > drop (:213-217): a prefix of the list
+  if (d.length - 2 > drop) {
+    while (d.lo < d.nrec) {
+      const auto v = S.info(d.lo);
+      if (d.length - R::i(v) - R::j(v) - 2 > drop) d.lo++;
+      else break;
     }
-    // max_q_extension / max_db_extension as the reference has them after its checks at this length
-    const bool q_open = length < tq0, d_open = length < td0;
-    const int max_q = q_open ? 100000 : tq0 - 1, max_d = d_open ? 100000 : td0 - 1;
-    // cumulative accessibility change of the extension (:156-212), kStage lengths at a time:
-    // the terms are fetched in parallel, the sums are sequential (lane 0: query side, lane 1: db side)
-    if ((length - 1) % kStage == 0) {
-      if (gl < kStage) {
-        const int len = length + gl;
-        if (len < tq0) {
-          if (flag == 0) {
-            const int t = q_start - len;
-            S.stage(0, gl) = qacc[t];
-            S.stage(1, gl) = qacc[t + 1];
-            S.stage(2, gl) = qcond[t + delta];
-          } else {
-            S.stage(0, gl) = qcond[q_start + len];
-          }
-        }
-        if (len < td0) {
-          if (flag == 0) {
-            S.stage(3, gl) = dcond[id_end + len];
-          } else {
-            const int t = id_start - len;
-            S.stage(3, gl) = dacc[t];
-            S.stage(4, gl) = dacc[t + 1];
-            S.stage(5, gl) = dcond[t + delta];
-          }
-        }
-      }
-      group_sync<kLds>();
-      if (gl == 0) {
-        for (int k = 0; k < kStage && length + k < tq0 && length + k <= S.cap_d(); k++) {
-          const int len = length + k;
-          double v;
-          if (flag == 0) {
-            if (len == 1) v = S.stage(0, k) - S.stage(1, k) + S.stage(2, k); // float arithmetic, as the reference
-            else v = acc_prev + S.stage(0, k) - S.stage(1, k) + S.stage(2, k);
-          } else {
-            if (len == 1) v = S.stage(0, k);
-            else v = acc_prev + S.stage(0, k);
-          }
-          acc_prev = v;
-          S.eq(len - 1) = v;
-        }
-      } else if (gl == 1) {
-        for (int k = 0; k < kStage && length + k < td0 && length + k <= S.cap_d(); k++) {
-          const int len = length + k;
-          double v;
-          if (flag == 0) {
-            if (len == 1) v = S.stage(3, k);
-            else v = acc_prev + S.stage(3, k);
-          } else {
-            if (len == 1) v = S.stage(3, k) - S.stage(4, k) + S.stage(5, k);
-            else v = acc_prev + S.stage(3, k) - S.stage(4, k) + S.stage(5, k);
-          }
-          acc_prev = v;
-          S.ed(len - 1) = v;
-        }
-      }
-    }
-    GP_MARK(1);
-    GP_COUNT(10);
-    const int cur = length % 3, d2 = (length + 1) % 3; // d2 = (length - 2) mod 3
-    // recycle the row of anti-diagonal length-3 for this one
-    for (int t = gl; t <= length; t += G) S.ptab(cur, t) = 0;
-    group_sync<kLds>();
-    // prune candidates with length - first - second - 2 > drop (:213-217): a prefix of the list
-    if (length - 2 > drop) {
-      while (lo < nrec) {
-        const auto v = S.info(lo);
-        if (length - R::i(v) - R::j(v) - 2 > drop) lo++;
-        else break;
-      }
-    }
-    GP_MARK(2);
-    const int dstart = nrec;
-    const int i_lo = length - max_d > 1 ? length - max_d : 1;
-    const int i_hi = max_q < length - 1 ? max_q : length - 1;
-    for (int i0 = i_lo; i0 <= i_hi && !overflow; i0 += G) {
-      const int i = i0 + gl, j = length - i;
-      int type1 = 0;
-      if (i <= i_hi) {
-        // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases
-        type1 = bp_type(sc, S.qb(i), S.db(j));
-        if (flag == 1) type1 = rtype_of(type1);
-        if (type1 != 0) {
-          const int pt = S.ptab(d2, i - 1);
-          if (pt == 0 || (wobble(type1) && wobble(pt))) {
-            for (int x = 1; x <= min_helix - 1; x++) {
-              int t = bp_type(sc, S.qb(i + x), S.db(j + x));
-              if (flag == 1) t = rtype_of(t);
-              if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
-                type1 = 0;
-                break;
-              }
+  }
+  GP_MARK(2);
+  const int dstart = d.nrec;
+  const int i_lo = d.length - max_d > 1 ? d.length - max_d : 1;
+  const int i_hi = max_q < d.length - 1 ? max_q : d.length - 1;
+  for (int i0 = i_lo; i0 <= i_hi && !d.overflow; i0 += G) {
+    const int i = i0 + gl, j = d.length - i;
+    int type1 = 0;
+    if (i <= i_hi) {
+      // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases
+      type1 = bp_type(sc, S.qb(i), S.db(j));
+      if (flag == 1) type1 = rtype_of(type1);
+      if (type1 != 0) {
+        const int pt = S.ptab(d2, i - 1);
+        if (pt == 0 || (wobble(type1) && wobble(pt))) {
+          for (int x = 1; x <= min_helix - 1; x++) {
+            int t = bp_type(sc, S.qb(i + x), S.db(j + x));
+            if (flag == 1) t = rtype_of(t);
+            if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
+              type1 = 0;
+              break;
             }
           }
         }
       }
-      unsigned long long vmask = __ballot(type1 != 0);
-      if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
-      GP_MARK(3);
-      GP_COUNT(11);
-      while (vmask) { // filled cells of this chunk, ascending i
-        GP_COUNT(12);
-        const int b = __builtin_ctzll(vmask);
-        vmask &= vmask - 1;
-        const int ci = i0 + b, cj = length - ci;
-        const int ctype = __shfl(type1, gbase + b);
-        // scan the live candidates [lo, dstart), G per round; strict '<' keeps the first
-        double bte = 1000000.0; // INF
-        int bk = lo;
-        for (int k0 = lo; k0 < dstart; k0 += G) {
-          GP_COUNT(13);
-          const int k = k0 + gl;
-          if (k < dstart) {
-            const auto v = S.info(k);
-            const int ri = R::i(v), rj = R::j(v);
-            if (ri < ci && rj < cj) {
-              // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
-              // offsets (ri, rj) and (ci, cj) from the start
-              double te;
-              if (flag == 0)
-                te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, S.qb(ci - 1), S.db(cj - 1),
-                                      S.qb(ri + 1), S.db(rj + 1));
-              else
-                te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, S.qb(ri + 1), S.db(rj + 1),
-                                      S.qb(ci - 1), S.db(cj - 1));
-              te += S.hyb(k);
-              if (te < bte) {
-                bte = te;
-                bk = k;
-              }
+    }
+    unsigned long long vmask = __ballot(type1 != 0);
+    if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
+    GP_MARK(3);
+    GP_COUNT(11);
+    while (vmask) { // filled cells of this chunk, ascending i
+      GP_COUNT(12);
+      const int b = __builtin_ctzll(vmask);
+      vmask &= vmask - 1;
+      const int ci = i0 + b, cj = d.length - ci;
+      const int ctype = __shfl(type1, gbase + b);
+      // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
+      double bte = 1000000.0; // INF
+      int bk = d.lo;
+      for (int k0 = d.lo; k0 < dstart; k0 += G) {
+        GP_COUNT(13);
+        const int k = k0 + gl;
+        if (k < dstart) {
+          const auto v = S.info(k);
+          const int ri = R::i(v), rj = R::j(v);
+          if (ri < ci && rj < cj) {
+            // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
+            // offsets (ri, rj) and (ci, cj) from the start
+            double te;
+            if (flag == 0)
+              te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, S.qb(ci - 1), S.db(cj - 1),
+                                    S.qb(ri + 1), S.db(rj + 1));
+            else
+              te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, S.qb(ri + 1), S.db(rj + 1),
+                                    S.qb(ci - 1), S.db(cj - 1));
+            te += S.hyb(k);
+            if (te < bte) {
+              bte = te;
+              bk = k;
             }
           }
         }
-        GP_MARK(4);
+      }
+      GP_MARK(4);
 #pragma unroll
-        for (int m = G / 2; m >= 1; m >>= 1) { // (energy, index) minimum over the group
-          const double ote = __shfl_xor(bte, m);
-          const int ok = __shfl_xor(bk, m);
-          if (ote < bte || (ote == bte && ok < bk)) {
-            bte = ote;
-            bk = ok;
-          }
+      for (int m = G / 2; m >= 1; m >>= 1) { // (energy, index) minimum over the group
+        const double ote = __shfl_xor(bte, m);
+        const int ok = __shfl_xor(bk, m);
+        if (ote < bte || (ote == bte && ok < bk)) {
+          bte = ote;
+          bk = ok;
         }
-        GP_MARK(5);
-        if (nrec >= S.cap_r()) {
-          overflow = true;
-          break;
-        }
-        if (lo >= dstart) bk = 0; // empty window: the reference reads stem_candidate[0] of an empty list
-        const int ptype = R::type(S.info(bk));
-        if (gl == 0) {
-          S.hyb(nrec) = bte;
-          S.info(nrec) = R::pack(ci, cj, bk, rtype_of(ctype), ptype);
-          S.ptab(cur, ci) = (uint8_t)ptype;
-        }
-        const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;
-        if (ie < min_e) {
-          min_e = ie;
-          min_a = first_a + S.eq(ci - 1) + S.ed(cj - 1);
-          min_length = length;
-          best = nrec;
-          if (flag == 0) {
-            min_q_start = q_start - ci;
-            min_db_start = db_start - cj;
-          } else {
-            min_id_start = id_start - cj;
-          }
-          min_q_len = q_length + ci;
-          min_db_len = db_length + cj;
-        }
-        nrec++;
-        GP_MARK(6);
       }
-      group_sync<kLds>();
-      GP_MARK(3);
+      GP_MARK(5);
+      if (d.nrec >= S.cap_r()) {
+        d.overflow = true;
+        break;
+      }
+      if (d.lo >= dstart) bk = 0; // empty window: the reference reads stem_candidate[0] of an empty list
+      const int ptype = R::type(S.info(bk));
+      if (gl == 0) {
+        S.hyb(d.nrec) = bte;
+        S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), ptype);
+        S.ptab(cur, ci) = (uint8_t)ptype;
+      }
+      const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;
+      if (ie < d.min_e) {
+        d.min_e = ie;
+        d.min_a = d.first_a + S.eq(ci - 1) + S.ed(cj - 1);
+        d.min_length = d.length;
+        d.best = d.nrec;
+        if (flag == 0) {
+          d.min_q_start = d.q_start - ci;
+          d.min_db_start = d.db_start - cj;
+        } else {
+          d.min_id_start = d.id_start - cj;
+        }
+        d.min_q_len = d.q_length + ci;
+        d.min_db_len = d.db_length + cj;
+      }
+      d.nrec++;
+      GP_MARK(6);
     }
-    if (overflow) break;
-    if (length - min_length >= drop) break;
-    if (!q_open && !d_open) break;
+    group_sync<kLds>();
+    GP_MARK(3);
   }
-  GP_MARK(7);
+  if (d.overflow) return true;
+  if (d.length - d.min_length >= drop) return true;
+  if (!q_open && !d_open) return true;
+  return false;
+}
+
+__device__ __forceinline__ DirResult dir_finish(const DirState &d, HitState &h, int flag) {
   DirResult r;
-  r.overflow = overflow;
-  r.best = (q_length - min_q_len != 0 && db_length - min_db_len != 0) ? best : 0;
-  h.id_start = min_id_start;
+  r.overflow = d.overflow;
+  r.best = (d.q_length - d.min_q_len != 0 && d.db_length - d.min_db_len != 0) ? d.best : 0;
+  h.id_start = d.min_id_start;
   if (flag == 0) {
-    h.q_sp = min_q_start;
-    h.db_sp = (int)min_db_start;
+    h.q_sp = d.min_q_start;
+    h.db_sp = (int)d.min_db_start;
   }
-  h.q_len = min_q_len;
-  h.db_len = min_db_len;
-  h.e_tot = min_e;
-  h.e_acc = min_a;
-  h.e_hyb = min_e - min_a;
+  h.q_len = d.min_q_len;
+  h.db_len = d.min_db_len;
+  h.e_tot = d.min_e;
+  h.e_acc = d.min_a;
+  h.e_hyb = d.min_e - d.min_a;
   return r;
 }
 
@@ -452,27 +507,28 @@ struct GapArgs {
   uint16_t *trace;   // mode 0 (LDS tiers): the first kTraceCap traced cells (i | j << 8) per direction of hit x
   const int64_t *bp_off;
   int32_t *bp_out;
+  unsigned long long *next_work; // LDS kernels: work counter (zero at launch) behind the statically assigned first hits
 };
 
-// One hit (index w of the work list) by one group.  kMode 0: extend, write the hit to out and
-// the number of traced-back pairs to bp_count[x]; 2: write the base pairs of the final
-// alignment at bp_off[w] (the extension is recomputed: only the ~3 % of hits that survive the
-// final filter are ever traced).
-template <int kMode, int G, bool kLds, class Store>
-__device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, int gbase, GapProf &prof) {
-  using R = typename Store::R;
+// Hit w of the work list.  kMode 0: extend, write the hit to out, the number of traced-back
+// pairs to bp_count[x] and the traced cells to the trace slot; 2: write the base pairs of the
+// final alignment at bp_off[w] (the extension is recomputed; only for the few final hits the
+// trace slots cannot describe).
+template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, int64_t w, HitCtx &c) {
   const SearchConst &sc = a.sc;
   const int64_t x = a.subset ? (int64_t)a.subset[w] : w;
-  const int query = a.in.query[x];
-  const int64_t qo = a.qb.off[query];
-  const uint8_t *qs = a.qb.enc + qo;
-  const int qn = a.qb.len[query] + 1;
-  const float *qacc = a.qb.acc + qo, *qcond = a.qb.cond + qo;
-  const uint8_t *ds = a.pg.seqs;
-  const int id = a.in.db_id[x];
-  const int64_t base = (int64_t)a.pg.start_pos[id] - id;
-  const float *dacc = a.pg.acc + base, *dcond = a.pg.cond + base;
-  HitState h;
+  c.x = x;
+  c.query = a.in.query[x];
+  const int64_t qo = a.qb.off[c.query];
+  c.qs = a.qb.enc + qo;
+  c.qn = a.qb.len[c.query] + 1;
+  c.qacc = a.qb.acc + qo;
+  c.qcond = a.qb.cond + qo;
+  c.id = a.in.db_id[x];
+  const int64_t base = (int64_t)a.pg.start_pos[c.id] - c.id;
+  c.dacc = a.pg.acc + base;
+  c.dcond = a.pg.cond + base;
+  HitState &h = c.h;
   h.q_sp = a.in.q_sp[x];
   h.db_sp = a.in.db_sp[x];
   h.q_len = a.in.q_len[x];
@@ -481,68 +537,74 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
   h.e_tot = a.in.e_tot[x];
   h.e_acc = a.in.e_acc[x];
   h.e_hyb = a.in.e_hyb[x];
-  const int diag_q = h.q_sp, diag_d = h.db_sp, diag_len = US(h.q_len); // the ungapped region
-
-  int ndiag = 0;
+  c.diag_q = h.q_sp; // the ungapped region
+  c.diag_d = h.db_sp;
+  c.diag_len = US(h.q_len);
+  c.ndiag = 0;
   if (kMode != 0) // GetBasePair, rna_interaction_search.cpp:371-385 (every lane counts; cheap)
-    for (int t = 0; t < diag_len; t++) ndiag += sc.bp_pair[(qs[diag_q + t] - 1) * 5 + (ds[diag_d + t] - 1)] != 0;
-  const bool unsorted = kMode != 0 && a.first_flag && a.first_flag[x]; // hit 0 keeps raw pair order (:314-317)
-  const int64_t out0 = kMode == 2 ? a.bp_off[w] : 0;
+    for (int t = 0; t < c.diag_len; t++)
+      c.ndiag += sc.bp_pair[(c.qs[c.diag_q + t] - 1) * 5 + (a.pg.seqs[c.diag_d + t] - 1)] != 0;
+  c.unsorted = kMode != 0 && a.first_flag && a.first_flag[x]; // hit 0 keeps raw pair order (:314-317)
+  c.out0 = kMode == 2 ? a.bp_off[w] : 0;
+  c.ovf = false;
+  c.nleft = 0;
+  c.nright = 0;
+}
 
-  bool ovf = false;
-  int nleft = 0, nright = 0;
-  for (int flag = 0; flag < 2 && !ovf; flag++) {
-    const int q_start = flag == 0 ? h.q_sp : h.q_sp + h.q_len - 1;
-    const int64_t db_start = flag == 0 ? (int64_t)h.db_sp : (int64_t)h.db_sp + h.db_len - 1;
-    GP_MARK(8);
-    const DirResult r = extend_dir_group<G, kLds>(sc, a.o, h, flag, qs, qn, qacc, qcond, ds, a.pg.nchars, dacc, dcond, S, gl,
-                                                  gbase, prof);
-    ovf = r.overflow;
-    if (!ovf) {
-      // traceback (:300-308, :409-424): from the arg-min cell through the predecessors.  The
-      // extension pass leaves the chain in the hit's trace slot, so that the base pairs of the
-      // few hits that survive the final filter can be written without extending them again.
-      int cnt = 0;
-      for (int k = r.best; k != 0; k = R::pred(S.info(k)), cnt++) {
-        if (kMode == 0 && kLds && gl == 0 && cnt < kTraceCap) {
-          const auto v = S.info(k);
-          a.trace[(x * 2 + flag) * kTraceCap + cnt] = (uint16_t)(R::i(v) | (R::j(v) << 8));
-        }
-      }
-      if (flag == 0) nleft = cnt;
-      else nright = cnt;
-      if (kMode == 2 && gl == 0) {
-        int t = 0;
-        for (int k = r.best; k != 0; k = R::pred(S.info(k)), t++) {
-          const auto v = S.info(k);
-          int64_t pos;
-          int qv, dv;
-          if (flag == 0) { // emitted outermost first = ascending positions
-            qv = q_start - R::i(v);
-            dv = (int)(db_start - R::j(v));
-            pos = unsorted ? out0 + ndiag + t : out0 + t;
-          } else { // emitted outermost first = descending positions
-            qv = q_start + R::i(v);
-            dv = (int)(db_start + R::j(v));
-            pos = unsorted ? out0 + ndiag + nleft + t : out0 + nleft + ndiag + (cnt - 1 - t);
-          }
-          a.bp_out[2 * pos] = qv;
-          a.bp_out[2 * pos + 1] = dv;
-        }
-      }
+// After a direction: traceback (:300-308, :409-424) from the arg-min cell through the
+// predecessors.  The extension pass leaves the chain in the hit's trace slot, so that the base
+// pairs of the few hits that survive the final filter can be written without extending them again.
+template <int kMode, bool kLds, class Store>
+__device__ __forceinline__ void hit_dir_done(const GapArgs &a, HitCtx &c, int flag, const DirState &d, const DirResult &r,
+                                             const Store &S, int gl) {
+  using R = typename Store::R;
+  c.ovf = r.overflow;
+  if (c.ovf) return;
+  int cnt = 0;
+  for (int k = r.best; k != 0; k = R::pred(S.info(k)), cnt++) {
+    if (kMode == 0 && kLds && gl == 0 && cnt < kTraceCap) {
+      const auto v = S.info(k);
+      a.trace[(c.x * 2 + flag) * kTraceCap + cnt] = (uint16_t)(R::i(v) | (R::j(v) << 8));
     }
-    group_sync<kLds>();
-    GP_MARK(7);
   }
+  if (flag == 0) c.nleft = cnt;
+  else c.nright = cnt;
+  if (kMode == 2 && gl == 0) {
+    int t = 0;
+    for (int k = r.best; k != 0; k = R::pred(S.info(k)), t++) {
+      const auto v = S.info(k);
+      int64_t pos;
+      int qv, dv;
+      if (flag == 0) { // emitted outermost first = ascending positions
+        qv = d.q_start - R::i(v);
+        dv = (int)(d.db_start - R::j(v));
+        pos = c.unsorted ? c.out0 + c.ndiag + t : c.out0 + t;
+      } else { // emitted outermost first = descending positions
+        qv = d.q_start + R::i(v);
+        dv = (int)(d.db_start + R::j(v));
+        pos = c.unsorted ? c.out0 + c.ndiag + c.nleft + t : c.out0 + c.nleft + c.ndiag + (cnt - 1 - t);
+      }
+      a.bp_out[2 * pos] = qv;
+      a.bp_out[2 * pos + 1] = dv;
+    }
+  }
+}
+
+// After both directions (or an overflow): lane 0 of the group writes the results of hit w.
+template <int kMode> __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const HitCtx &c, int gl) {
   if (gl != 0) return;
+  const SearchConst &sc = a.sc;
+  const HitState &h = c.h;
+  const uint8_t *ds = a.pg.seqs;
   if (kMode == 0) {
-    a.overflow[w] = ovf ? 1 : 0;
-    if (!ovf) {
+    a.overflow[w] = c.ovf ? 1 : 0;
+    if (!c.ovf) {
+      const int64_t x = c.x;
       a.tier_out[x] = (uint8_t)a.tier_id;
-      a.bp_count[x] = nleft | (nright << 16);
+      a.bp_count[x] = c.nleft | (c.nright << 16);
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
-      const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, qn, ds, a.pg.nchars);
-      const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, qs, qn,
+      const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, c.qs, c.qn, ds, a.pg.nchars);
+      const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, c.qs, c.qn,
                                              ds, a.pg.nchars);
       double e = h.e_tot, hy = h.e_hyb;
       e += d0;
@@ -553,20 +615,20 @@ __device__ void gapped_one(const GapArgs &a, int64_t w, const Store &S, int gl, 
       a.out.db_sp[x] = h.db_sp;
       a.out.q_len[x] = h.q_len;
       a.out.db_len[x] = h.db_len;
-      a.out.db_id[x] = id;
+      a.out.db_id[x] = c.id;
       a.out.db_id_start[x] = h.id_start;
-      a.out.query[x] = query;
+      a.out.query[x] = c.query;
       a.out.e_acc[x] = h.e_acc;
       a.out.e_hyb[x] = hy;
       a.out.e_tot[x] = e;
     }
-  } else if (!ovf) {
+  } else if (!c.ovf) {
     int t = 0;
-    const int64_t d0 = unsorted ? out0 : out0 + nleft;
-    for (int u = 0; u < diag_len; u++)
-      if (sc.bp_pair[(qs[diag_q + u] - 1) * 5 + (ds[diag_d + u] - 1)] != 0) {
-        a.bp_out[2 * (d0 + t)] = diag_q + u;
-        a.bp_out[2 * (d0 + t) + 1] = diag_d + u;
+    const int64_t d0 = c.unsorted ? c.out0 : c.out0 + c.nleft;
+    for (int u = 0; u < c.diag_len; u++)
+      if (sc.bp_pair[(c.qs[c.diag_q + u] - 1) * 5 + (ds[c.diag_d + u] - 1)] != 0) {
+        a.bp_out[2 * (d0 + t)] = c.diag_q + u;
+        a.bp_out[2 * (d0 + t) + 1] = c.diag_d + u;
         t++;
       }
   }
@@ -588,24 +650,73 @@ __global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const ui
   bp_count[w] = c + (ntrace[x] & 0xFFFF) + (int)((uint32_t)ntrace[x] >> 16);
 }
 
+// LDS form.  The grid is what is resident at once; every group takes hits from a global work
+// counter.  The groups of a wavefront share one loop whose body is "one anti-diagonal of whatever
+// hit / direction the group is at", and they change direction / hit only at the iterations that
+// are multiples of P = the drop-out length: a direction without any improvement - nine in ten -
+// takes exactly P anti-diagonals, so the groups that started together also finish together and
+// their (latency-bound) transitions stay one convergent piece of code, while a group with a
+// longer extension just misses a boundary or two instead of holding up the whole wavefront
+// (PROF build: with hit-by-hit lockstep 36 % of the wave time was spent waiting for the longest
+// extension; with free-running groups 40 % on each other's divergent transitions).
 template <int kMode, class T, class Rec>
 __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_lds(GapArgs a) {
   __shared__ LdsState<T, Rec> lds[T::kGroups];
-  constexpr int kLdsGroup = T::kG;
-  const int gl = threadIdx.x & (kLdsGroup - 1);
-  const int gbase = (threadIdx.x & 63) & ~(kLdsGroup - 1);
-  const int gid = threadIdx.x / kLdsGroup;
+  constexpr int G = T::kG;
+  const int gl = threadIdx.x & (G - 1);
+  const int gbase = (threadIdx.x & 63) & ~(G - 1);
+  const int gid = threadIdx.x / G;
   const LdsStore<T, Rec> S{lds[gid]};
   const int64_t ngroups = (int64_t)gridDim.x * T::kGroups;
   GapProf prof;
   prof.start();
-  for (int64_t w = (int64_t)blockIdx.x * T::kGroups + gid; w < a.n; w += ngroups) {
-    gapped_one<kMode, kLdsGroup, true>(a, w, S, gl, gbase, prof);
-    GP_MARK(9);
+  int64_t w = (int64_t)blockIdx.x * T::kGroups + gid;
+  enum { kLoad, kInit, kRun, kFinished, kDone };
+  int phase = w < a.n ? kLoad : kDone, flag = 0;
+  const int period = a.o.drop_w_gap > 1 ? a.o.drop_w_gap : 1;
+  int tick = 0; // iterations since the last boundary
+  HitCtx c;
+  DirState d;
+  while (__ballot(phase != kDone) != 0) {
+    GP_MARK(14);
+    if (tick == 0) {
+      if (phase == kFinished) {
+        const DirResult r = dir_finish(d, c.h, flag);
+        hit_dir_done<kMode, true>(a, c, flag, d, r, S, gl);
+        group_sync<true>();
+        GP_MARK(7);
+        if (c.ovf || flag == 1) {
+          hit_store<kMode>(a, w, c, gl);
+          unsigned long long nw = 0;
+          if (gl == 0) nw = (unsigned long long)ngroups + atomicAdd(a.next_work, 1ull);
+          w = (int64_t)__shfl(nw, gbase);
+          phase = w < a.n ? kLoad : kDone;
+          GP_MARK(9);
+        } else {
+          flag = 1;
+          phase = kInit;
+        }
+      }
+      if (phase == kLoad) {
+        hit_load<kMode>(a, w, c);
+        flag = 0;
+        phase = kInit;
+        GP_MARK(8);
+      }
+      if (phase == kInit) {
+        dir_init<G, true>(a.sc, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
+        phase = kRun;
+        GP_MARK(0);
+      }
+    }
+    GP_MARK(15);
+    if (phase == kRun && dir_step<G, true>(a.sc, a.o, c, flag, S, gl, gbase, d, prof)) phase = kFinished;
+    tick = tick + 1 == period ? 0 : tick + 1;
   }
   prof.flush(a.tier_id * 2 + (kMode != 0));
 }
 
+// HBM-scratch form: one wavefront per hit, so the plain nesting (hit, direction, anti-diagonal).
 template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs a, GapScratch scratch) {
   const int gl = threadIdx.x;
   uint8_t *mine = scratch.base + (size_t)blockIdx.x * scratch.bytes_per_thread; // one block of scratch per wavefront
@@ -622,8 +733,22 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
   S.db_ = S.qb_ + S.capd + 16;
   GapProf prof;
   prof.start();
+  HitCtx c;
+  DirState d;
   for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) {
-    gapped_one<kMode, 64, false>(a, w, S, gl, 0, prof);
+    hit_load<kMode>(a, w, c);
+    for (int flag = 0; flag < 2 && !c.ovf; flag++) {
+      GP_MARK(8);
+      dir_init<64, false>(a.sc, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
+      GP_MARK(0);
+      while (!dir_step<64, false>(a.sc, a.o, c, flag, S, gl, 0, d, prof)) {
+      }
+      const DirResult r = dir_finish(d, c.h, flag);
+      hit_dir_done<kMode, false>(a, c, flag, d, r, S, gl);
+      group_sync<false>();
+      GP_MARK(7);
+    }
+    hit_store<kMode>(a, w, c, gl);
     GP_MARK(9);
   }
   prof.flush(3 * 2 + (kMode != 0));
@@ -651,7 +776,8 @@ size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
 namespace {
 template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode, hipStream_t s) {
   const int64_t want = (a.n + T::kGroups - 1) / T::kGroups;
-  const dim3 grid((unsigned)std::min<int64_t>(want, 256 * 4 * 8)), blk(T::kG * T::kGroups);
+  const dim3 grid((unsigned)std::min<int64_t>(want, 256 * T::kWgPerCu)), blk(T::kG * T::kGroups);
+  if (hipError_t e = hipMemsetAsync(a.next_work, 0, sizeof(unsigned long long), s); e != hipSuccess) return e;
   if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec>), grid, blk, 0, s, a);
   else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec>), grid, blk, 0, s, a);
   return hipGetLastError();
@@ -661,9 +787,9 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
-                             const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
+                             const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, trace, bp_off, bp_out};
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, trace, bp_off, bp_out, next_work};
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
   return launch_tier<Tier2, Rec64>(a, mode, s);
@@ -674,7 +800,7 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
                               const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, 3, first_flag, bp_count, nullptr, bp_off, bp_out};
+  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, 3, first_flag, bp_count, nullptr, bp_off, bp_out, nullptr};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
   else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);

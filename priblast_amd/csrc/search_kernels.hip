@@ -11,6 +11,8 @@
 // float-derived accessibilities, summed in the reference's order (-ffp-contract=off).
 #include "search_kernels.hpp"
 
+#include "../../include/priblast_hip.h"
+
 #include "search_device.hpp"
 
 namespace prb {
@@ -231,6 +233,26 @@ __global__ __launch_bounds__(kBlock) void k_gather_hits(HitSoA s, const uint32_t
   d.e_tot[i] = s.e_tot[j];
 }
 
+// SoA hits -> the C ABI's records (include/priblast_hip.h), so that one copy brings them to the host
+__global__ __launch_bounds__(kBlock) void k_pack_hits(HitSoA s, int64_t n, prb_hit *out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  prb_hit h;
+  h.q_sp = s.q_sp[i];
+  h.db_sp = s.db_sp[i];
+  h.q_len = s.q_len[i];
+  h.db_len = s.db_len[i];
+  h.db_id = s.db_id[i];
+  h.db_id_start = s.db_id_start[i];
+  h.e_acc = s.e_acc[i];
+  h.e_hyb = s.e_hyb[i];
+  h.e_tot = s.e_tot[i];
+  h.query = s.query[i];
+  h.bp_count = 0;
+  h.bp_offset = 0;
+  out[i] = h;
+}
+
 // keep[i] = 1 unless E_i > threshold.  A hit above the threshold is flagged by CheckRedundancy
 // the moment the sweep reaches it and never flags anything else (as the contained hit of an
 // earlier scan it loses: E_a <= threshold < E_b), so it can be dropped BEFORE the sort.
@@ -392,6 +414,11 @@ hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *ds
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_gather_hits, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_pack_hits(const HitSoA &src, int64_t n, void *out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_hits, grid_for(n), dim3(kBlock), 0, s, src, n, static_cast<prb_hit *>(out));
   return hipGetLastError();
 }
 hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s) {

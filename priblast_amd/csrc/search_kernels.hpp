@@ -97,6 +97,8 @@ hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, u
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s);
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t *dst, int64_t n, hipStream_t s);
+// out: n records of prb_hit (include/priblast_hip.h) in device memory
+hipError_t launch_pack_hits(const HitSoA &src, int64_t n, void *out, hipStream_t s);
 hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
 hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s);
@@ -127,7 +129,8 @@ size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
-                             const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
+                             const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work /* 8 bytes of scratch */,
+                             hipStream_t s);
 // Trace slots: the extension pass (mode 0, LDS tiers) leaves the first kTraceCap cells (i | j << 8)
 // of each direction's traceback chain of hit x at trace[(2x + direction) * kTraceCap ...];
 // launch_bp_expand writes the base pairs of the final hits from them (hits of the wave kernel or

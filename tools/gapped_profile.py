@@ -18,7 +18,7 @@ from priblast_amd import capi  # noqa: E402
 capi.LIB_PATH = os.path.join(ROOT, "priblast_amd", "lib", "libpriblast_hip_prof.so")
 REGIONS = ["dir setup (windows)", "acc staging", "ptab reset + prune", "cell check", "candidate scan",
            "group reduce", "cell update", "dir/hit epilogue", "hit prologue", "hit loop tail",
-           "#anti-diagonal steps", "#chunks", "#fill iterations", "#scan rounds"]
+           "#anti-diagonal steps", "#chunks", "#fill iterations", "#scan rounds", "loop top", "boundary block (others)"]
 
 
 def main():
@@ -44,18 +44,18 @@ def main():
     print(f"hits: seed {counts[0]}, post-ungapped {counts[1]}, final {counts[2]}")
     for s in ("gapped", "gapped_t1", "gapped_slow", "traceback", "traceback_slow"):
         print(f"  {s}: {ctx.stage_ms(s)[0]:.1f} ms")
-    total = allv[:, :10].sum()
+    total = allv[:, :10].sum() + allv[:, 14:16].sum()
     names = {0: "tier 0 extend", 1: "tier 0 trace", 2: "tier 1 extend", 3: "tier 1 trace", 6: "wave extend", 7: "wave trace"}
     # NOTE: the accumulators live in lane 0 of each wavefront, so a region also collects the time
     # lane 0's group spends masked off while other groups of the wavefront are still busy
     # (e.g. "dir/hit epilogue" = waiting for the longest extension of the wavefront).
     for kind, name in names.items():
         v = allv[kind]
-        cyc = v[:10].sum()
+        cyc = v[:10].sum() + v[14:16].sum()
         if cyc == 0:
             continue
         print(f"{name}: {cyc / total * 100:.1f} % of all gapped wave-cycles")
-        for i in range(10):
+        for i in list(range(10)) + [14, 15]:
             print(f"  {REGIONS[i]:24s} {v[i] / cyc * 100:6.2f} %")
         print("  wave-level counts: " + ", ".join(f"{REGIONS[i]} {v[i]:.3g}" for i in range(10, 14)))
 
