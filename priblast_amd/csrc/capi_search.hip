@@ -28,7 +28,7 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
                       const int64_t *out_off, int W, int delta, float *d_acc, float *d_cond);
 
 struct SearchConstMem {
-  DevBuf ints, bulge, div100;
+  DevBuf ints, bulge;
   SearchConst view{};
 };
 
@@ -196,10 +196,6 @@ int prb_search_const_upload(prb_ctx *ctx) {
   if ((rc = m->bulge.ensure(bulge.size() * 8))) return rc;
   PRB_HIP(hipMemcpy(m->ints.p, ints.data(), ints.size() * 4, hipMemcpyHostToDevice));
   PRB_HIP(hipMemcpy(m->bulge.p, bulge.data(), bulge.size() * 8, hipMemcpyHostToDevice));
-  std::vector<double> d100(4096);
-  for (int z = 0; z < 4096; z++) d100[z] = (double)(z - 2048) / 100.0;
-  if ((rc = m->div100.ensure(d100.size() * 8))) return rc;
-  PRB_HIP(hipMemcpy(m->div100.p, d100.data(), d100.size() * 8, hipMemcpyHostToDevice));
   for (int t = 0; t < 7; t++)
     if (p.rtype[t] != (t == 0 ? 0 : ((t - 1) ^ 1) + 1)) {
       set_error("parameter file: rtype is not the expected pair-type involution");
@@ -217,7 +213,6 @@ int prb_search_const_upload(prb_ctx *ctx) {
   v.dangle5 = b + o_d5;
   v.dangle3 = b + o_d3;
   v.bulge = m->bulge.as<double>();
-  v.div100 = m->div100.as<double>();
   v.bp_rows = 0;
   for (int a = 1; a < 5; a++)
     for (int c = 0; c < 5; c++) v.bp_rows |= (uint64_t)(p.bp_pair[a][c] & 7) << (15 * (a - 1) + 3 * c);
@@ -232,7 +227,6 @@ void prb_search_const_free(prb_ctx *ctx) {
     auto *m = static_cast<SearchConstMem *>(ctx->search_const);
     m->ints.release();
     m->bulge.release();
-    m->div100.release();
     delete m;
     ctx->search_const = nullptr;
   }
@@ -753,11 +747,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       (rc = w.trace.ensure((size_t)nung * 2 * kTraceCap * sizeof(uint16_t))))
     return rc;
   // The cascade of kernels a hit goes through until one has the capacity for it: LDS tier 0
-  // (8 lanes per hit), LDS tier 1 (16 lanes), then the wave-per-hit kernel with HBM scratch.
+  // (8 lanes per hit), LDS tier 1 (16 lanes), LDS tier 2 (a wavefront per hit), then the
+  // wave-per-hit kernel with HBM scratch of any size.
   // The environment switches exist for the tests: they force the rarely taken kernels.
-  std::vector<int> cascade{0, 1, 3};
+  std::vector<int> cascade{0, 1, 2, 3};
   if (getenv("PRB_FORCE_WAVE_GAPPED")) cascade = {3};
-  else if (getenv("PRB_GAPPED_SKIP_TIER1")) cascade = {2, 3}; // the large-capacity LDS instantiation
+  else if (getenv("PRB_GAPPED_SKIP_TIER1")) cascade = {2, 3};
   else if (getenv("PRB_GAPPED_SKIP_TIER0")) cascade = {1, 3};
   auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
     gs.cap_diag = cap_diag;

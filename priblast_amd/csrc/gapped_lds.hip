@@ -62,17 +62,16 @@ struct GapProf {
 namespace {
 
 constexpr int kInitStage = 16; // extension lengths whose accessibility sums dir_init prepares
-constexpr int kStageHbm = 16; // extension lengths whose accessibility terms are staged at a time (HBM form)
 // LDS tiers: lanes per hit, (anti-diagonals, filled cells) per direction, groups (= hits) per
 // workgroup, staged extension lengths (<= lanes per hit)
 struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
-  static constexpr int kG = 8, kCapD = 32, kCapR = 56, kGroups = 32, kStage = 8, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
 };
 struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
-  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kStage = 16, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
 };
-struct Tier2 { // 9.6 KB per hit, 2 workgroups of 128 threads per CU (testing only)
-  static constexpr int kG = 16, kCapD = 128, kCapR = 448, kGroups = 8, kStage = 16, kWavesPerSimd = 1, kWgPerCu = 1;
+struct Tier2 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
+  static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -87,6 +86,16 @@ struct Rec32 {
   static __device__ __forceinline__ int pred(word v) { return (v >> 14) & 0x7F; }
   static __device__ __forceinline__ int type(word v) { return (v >> 21) & 7; }
 };
+struct Rec32W { // tier 2
+  using word = uint32_t; // i:8 | j:8 | pred:9 | type:3 | ptype:3
+  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
+    return (word)i | ((word)j << 8) | ((word)pred << 16) | ((word)type << 25) | ((word)ptype << 28);
+  }
+  static __device__ __forceinline__ int i(word v) { return v & 0xFF; }
+  static __device__ __forceinline__ int j(word v) { return (v >> 8) & 0xFF; }
+  static __device__ __forceinline__ int pred(word v) { return (v >> 16) & 0x1FF; }
+  static __device__ __forceinline__ int type(word v) { return (v >> 25) & 7; }
+};
 struct Rec64 {
   using word = uint64_t; // i:16 | j:16 | type:4 | ptype:4 | pred:24
   static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
@@ -98,14 +107,13 @@ struct Rec64 {
   static __device__ __forceinline__ int pred(word v) { return (int)(v >> 40); }
   static __device__ __forceinline__ int type(word v) { return (int)((v >> 32) & 0xF); }
 };
-static_assert(Tier0::kCapR * 8 >= 6 * kInitStage * 4 && Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127 && Tier0::kStage <= Tier0::kG, "Rec32 field widths");
+static_assert(Tier2::kCapD + 16 <= 255 && Tier2::kCapR <= 512 && Tier0::kCapR * 8 >= 6 * kInitStage * 4 && Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127, "Rec32 field widths");
 
 template <class T, class Rec> struct LdsState {
   double eq[T::kCapD], ed[T::kCapD];
   double hyb[T::kCapR];
   typename Rec::word info[T::kCapR];
-  float stage[6][T::kStage];    // accessibility terms of the next kStage extension lengths
-  uint8_t ptab[3][T::kCapD + 16];
+  uint8_t ptab[3][T::kCapD + 4];
   uint8_t qb[T::kCapD + 16], db[T::kCapD + 16]; // bases along the extension, 0 = end of sequence / masked
 };
 template <class T, class Rec> struct LdsStore {
@@ -118,18 +126,16 @@ template <class T, class Rec> struct LdsStore {
   __device__ __forceinline__ double &hyb(int r) const { return s.hyb[r]; }
   __device__ __forceinline__ typename Rec::word &info(int r) const { return s.info[r]; }
   __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return s.ptab[row][i]; }
-  __device__ __forceinline__ int ptab_len() const { return T::kCapD + 16; }
+  __device__ __forceinline__ int ptab_len() const { return T::kCapD + 4; } // indices 0..kCapD, a multiple of 4
+  __device__ __forceinline__ int win_len() const { return T::kCapD + 16; }
   __device__ __forceinline__ uint8_t &qb(int t) const { return s.qb[t]; }
   __device__ __forceinline__ uint8_t &db(int t) const { return s.db[t]; }
-  __device__ __forceinline__ float &stage(int k, int t) const { return s.stage[k][t]; }
-  __device__ __forceinline__ constexpr int nstage() const { return T::kStage; }
 };
 struct HbmStore { // one block of the scratch per group
   using R = Rec64;
   double *eq_, *ed_, *hyb_;
   uint64_t *info_;
   uint8_t *ptab_, *qb_, *db_;
-  float *stage_;
   int capd, capr;
   __device__ __forceinline__ int cap_d() const { return capd; }
   __device__ __forceinline__ int cap_r() const { return capr; }
@@ -137,12 +143,11 @@ struct HbmStore { // one block of the scratch per group
   __device__ __forceinline__ double &ed(int i) const { return ed_[i]; }
   __device__ __forceinline__ double &hyb(int r) const { return hyb_[r]; }
   __device__ __forceinline__ uint64_t &info(int r) const { return info_[r]; }
-  __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return ptab_[(size_t)row * (capd + 16) + i]; }
-  __device__ __forceinline__ int ptab_len() const { return capd + 16; }
+  __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return ptab_[(size_t)row * (capd + 4) + i]; }
+  __device__ __forceinline__ int ptab_len() const { return capd + 4; }
+  __device__ __forceinline__ int win_len() const { return capd + 16; }
   __device__ __forceinline__ uint8_t &qb(int t) const { return qb_[t]; }
   __device__ __forceinline__ uint8_t &db(int t) const { return db_[t]; }
-  __device__ __forceinline__ float &stage(int k, int t) const { return stage_[k * kStageHbm + t]; }
-  __device__ __forceinline__ constexpr int nstage() const { return kStageHbm; }
 };
 
 // State traffic inside a group is produced and consumed by lanes of ONE wavefront; its
@@ -189,44 +194,50 @@ struct DirState {
 // Cumulative accessibility change of the extension (gapped_extension.cpp:156-212) for the nb
 // lengths from L0 on: the terms are fetched in parallel into the float scratch sf(term, t),
 // the sums are sequential (lane 0: query side -> eq[], lane 1: db side -> ed[]).
-template <int G, bool kLds, class Store, class SF>
+template <int G, bool kLds, class Store>
 __device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, const Store &S, int gl, DirState &d, int L0,
-                                          int nb, SF sf) {
+                                          int nb, float *scratch /* [6][nb], or nullptr: no parallel fetch */) {
   const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
-  for (int t = gl; t < nb; t += G) {
-    const int len = L0 + t;
-    if (len < d.tq0) {
-      if (flag == 0) {
-        const int p = d.q_start - len;
-        sf(0, t) = qacc[p];
-        sf(1, t) = qacc[p + 1];
-        sf(2, t) = qcond[p + delta];
-      } else {
-        sf(0, t) = qcond[d.q_start + len];
+  // term k of length len: query side k = 0..2, db side k = 3..5
+  auto term = [&](int k, int len) -> float {
+    if (flag == 0) {
+      const int p = d.q_start - len;
+      return k == 0 ? qacc[p] : k == 1 ? qacc[p + 1] : k == 2 ? qcond[p + delta] : dcond[d.id_end + len];
+    }
+    const int p = d.id_start - len;
+    return k == 0 ? qcond[d.q_start + len] : k == 3 ? dacc[p] : k == 4 ? dacc[p + 1] : dcond[p + delta];
+  };
+  if (scratch) {
+    for (int t = gl; t < nb; t += G) {
+      const int len = L0 + t;
+      if (len < d.tq0) {
+        scratch[0 * nb + t] = term(0, len);
+        if (flag == 0) {
+          scratch[1 * nb + t] = term(1, len);
+          scratch[2 * nb + t] = term(2, len);
+        }
+      }
+      if (len < d.td0) {
+        scratch[3 * nb + t] = term(3, len);
+        if (flag == 1) {
+          scratch[4 * nb + t] = term(4, len);
+          scratch[5 * nb + t] = term(5, len);
+        }
       }
     }
-    if (len < d.td0) {
-      if (flag == 0) {
-        sf(3, t) = dcond[d.id_end + len];
-      } else {
-        const int p = d.id_start - len;
-        sf(3, t) = dacc[p];
-        sf(4, t) = dacc[p + 1];
-        sf(5, t) = dcond[p + delta];
-      }
-    }
+    group_sync<kLds>();
   }
-  group_sync<kLds>();
+  auto get = [&](int k, int t) -> float { return scratch ? scratch[k * nb + t] : term(k, L0 + t); };
   if (gl == 0) {
     for (int k = 0; k < nb && L0 + k < d.tq0 && L0 + k <= S.cap_d(); k++) {
       const int len = L0 + k;
       double v;
       if (flag == 0) {
-        if (len == 1) v = sf(0, k) - sf(1, k) + sf(2, k); // float arithmetic, as the reference
-        else v = d.acc_prev + sf(0, k) - sf(1, k) + sf(2, k);
+        if (len == 1) v = get(0, k) - get(1, k) + get(2, k); // float arithmetic, as the reference
+        else v = d.acc_prev + get(0, k) - get(1, k) + get(2, k);
       } else {
-        if (len == 1) v = sf(0, k);
-        else v = d.acc_prev + sf(0, k);
+        if (len == 1) v = get(0, k);
+        else v = d.acc_prev + get(0, k);
       }
       d.acc_prev = v;
       S.eq(len - 1) = v;
@@ -236,11 +247,11 @@ __device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, 
       const int len = L0 + k;
       double v;
       if (flag == 0) {
-        if (len == 1) v = sf(3, k);
-        else v = d.acc_prev + sf(3, k);
+        if (len == 1) v = get(3, k);
+        else v = d.acc_prev + get(3, k);
       } else {
-        if (len == 1) v = sf(3, k) - sf(4, k) + sf(5, k);
-        else v = d.acc_prev + sf(3, k) - sf(4, k) + sf(5, k);
+        if (len == 1) v = get(3, k) - get(4, k) + get(5, k);
+        else v = d.acc_prev + get(3, k) - get(4, k) + get(5, k);
       }
       d.acc_prev = v;
       S.ed(len - 1) = v;
@@ -287,7 +298,7 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
 
   // bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407);
   // the first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154)
-  const int wn = S.ptab_len();
+  const int wn = S.win_len();
   d.tq0 = wn;
   d.td0 = wn;
   for (int t = gl; t < wn; t += G) {
@@ -301,8 +312,8 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
     if (t >= 1 && dc == 0 && t < d.td0) d.td0 = t;
   }
   {
-    uint32_t *pz = reinterpret_cast<uint32_t *>(&S.ptab(0, 0)); // 3 rows of wn bytes, wn a multiple of 4
-    for (int t = gl; t < 3 * wn / 4; t += G) pz[t] = 0;
+    uint32_t *pz = reinterpret_cast<uint32_t *>(&S.ptab(0, 0)); // 3 rows, each a multiple of 4 bytes
+    for (int t = gl; t < 3 * S.ptab_len() / 4; t += G) pz[t] = 0;
   }
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) {
@@ -315,8 +326,7 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
   // the cell list is still empty, so its energies' storage serves as the float scratch
   d.acc_prev = 0;
   {
-    float *scratch = reinterpret_cast<float *>(&S.hyb(0));
-    stage_acc<G, kLds>(c, flag, delta, S, gl, d, 1, kInitStage, [&](int k, int t) -> float & { return scratch[k * kInitStage + t]; });
+    stage_acc<G, kLds>(c, flag, delta, S, gl, d, 1, kInitStage, reinterpret_cast<float *>(&S.hyb(0)));
   }
   int type0 = bp_type(sc, S.qb(0), S.db(0));
   if (flag == 0) type0 = rtype_of(type0);
@@ -336,7 +346,6 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
                                          DirState &d, GapProf &prof) {
   using R = typename Store::R;
   const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
-  const int kStage = S.nstage();
   const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
   d.length++;
   if (d.length > S.cap_d()) {
@@ -346,9 +355,10 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
   // max_q_extension / max_db_extension as the reference has them after its checks at this d.length
   const bool q_open = d.length < d.tq0, d_open = d.length < d.td0;
   const int max_q = q_open ? 100000 : d.tq0 - 1, max_d = d_open ? 100000 : d.td0 - 1;
-  // cumulative accessibility change beyond the lengths dir_init staged, kStage lengths at a time
-  if ((d.length - 1) % kStage == 0 && d.length > kInitStage)
-    stage_acc<G, kLds>(c, flag, delta, S, gl, d, d.length, kStage, [&](int k, int t) -> float & { return S.stage(k, t); });
+  // cumulative accessibility change beyond the lengths dir_init prepared (one direction in ten
+  // gets here): lanes 0 / 1 read the terms straight from HBM
+  if ((d.length - 1) % kInitStage == 0 && d.length > kInitStage)
+    stage_acc<G, kLds>(c, flag, delta, S, gl, d, d.length, kInitStage, (float *)nullptr);
   GP_MARK(1);
   GP_COUNT(10);
   const int cur = d.length % 3, d2 = (d.length + 1) % 3; // d2 = (d.length - 2) mod 3
@@ -727,9 +737,8 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
   S.ed_ = S.eq_ + S.capd;
   S.hyb_ = S.ed_ + S.capd;
   S.info_ = reinterpret_cast<uint64_t *>(S.hyb_ + S.capr);
-  S.stage_ = reinterpret_cast<float *>(S.info_ + S.capr);
-  S.ptab_ = reinterpret_cast<uint8_t *>(S.stage_ + 6 * kStageHbm);
-  S.qb_ = S.ptab_ + 3 * ((size_t)S.capd + 16);
+  S.ptab_ = reinterpret_cast<uint8_t *>(S.info_ + S.capr);
+  S.qb_ = S.ptab_ + 3 * ((size_t)S.capd + 4);
   S.db_ = S.qb_ + S.capd + 16;
   GapProf prof;
   prof.start();
@@ -769,7 +778,7 @@ extern "C" int prb_debug_gap_profile(unsigned long long *out, int reset) {
 #endif
 
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
-  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 6 * kStageHbm * 4 + 5 * ((size_t)cap_diag + 16);
+  size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 4) + 2 * ((size_t)cap_diag + 16);
   return (b + 255) & ~(size_t)255;
 }
 
@@ -792,7 +801,7 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
   GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, trace, bp_off, bp_out, next_work};
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
-  return launch_tier<Tier2, Rec64>(a, mode, s);
+  return launch_tier<Tier2, Rec32W>(a, mode, s);
 }
 
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,

@@ -20,9 +20,14 @@ __device__ __forceinline__ int bp_type(const SearchConst &sc, int a, int b) {
   return a == 0 ? 0 : (int)((sc.bp_rows >> (15 * (a - 1) + 3 * b)) & 7);
 }
 __device__ __forceinline__ int rtype_of(int t) { return t == 0 ? 0 : ((t - 1) ^ 1) + 1; } // energy_par.hpp:26
-// z / 100.0 for an integer energy z (0.01 kcal/mol): table of the exact IEEE quotients
-__device__ __forceinline__ double div100(const SearchConst &sc, int z) {
-  return (unsigned)(z + 2048) < 4096u ? sc.div100[z + 2048] : (double)z / 100.0;
+// z / 100.0 for an integer energy z (0.01 kcal/mol), correctly rounded without a division or
+// a table look-up: one Newton step on z * fl(1/100) with fused multiply-adds.  Bit-identical to the
+// IEEE quotient for every |z| <= 100000 (exhaustive check: tests/div100_check.c).
+__device__ __forceinline__ double div100(const SearchConst &, int z) {
+  const double zd = (double)z, r100 = 0.01;
+  const double q0 = zd * r100;
+  const double r = fma(-q0, 100.0, zd);
+  return fma(r, r100, q0);
 }
 
 
@@ -88,8 +93,7 @@ __device__ __forceinline__ double loop_energy_abcd(const SearchConst &sc, int ty
     i2 = stack ? T::kZero : (u == 1 ? st : T::kTau + type);
     i3 = (stack || u == 1) ? T::kZero : T::kTau + type2;
   }
-  const int z = sc.tab[i1] + sc.tab[i2] + sc.tab[i3];
-  return sc.div100[(z + 2048) & 4095];
+  return div100(sc, sc.tab[i1] + sc.tab[i2] + sc.tab[i3]);
 }
 
 // GetBPType, gapped_extension.cpp:321-338

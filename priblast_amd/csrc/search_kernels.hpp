@@ -36,7 +36,6 @@ struct SearchConst {
   const int32_t *dangle5;   // [8][5]
   const int32_t *dangle3;   // [8][5]
   const double *bulge;      // [64]: bulge37[u] for u <= 30, logarithmic extrapolation beyond
-  const double *div100;     // [4096]: (double)(z - 2048) / 100.0, the exact quotient the reference computes
   int32_t terminal_au;
   // BP_pair (energy_par.hpp:17-23) packed 3 bits per entry, row a (1..4) at bit 15*(a-1);
   // rtype (energy_par.hpp:26) is the involution ((t-1)^1)+1, checked on the host
@@ -123,7 +122,7 @@ size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
 // two extensions of hit x; mode 2: write the base pairs of list entry i at bp_off[i] (hits
 // beyond the capacity are skipped).  launch_bp_count: total pairs per list entry.
 // launch_gapped_lds: a group of lanes per hit, state in LDS with fixed capacities: tier 0 = 8 lanes,
-// 32 anti-diagonals; tier 1 = 16 lanes, 64 anti-diagonals; tier 2 = 16 lanes, 128 (testing only).
+// 32 anti-diagonals; tier 1 = 16 lanes, 64 anti-diagonals; tier 2 = 64 lanes, 128 anti-diagonals.
 // launch_gapped_wave: one wavefront per hit, state in the HBM scratch (`scratch.nthreads`
 // wavefronts, `bytes_per_thread` bytes each = gapped_wave_scratch_bytes(cap_diag, cap_rec)).
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,

@@ -81,3 +81,14 @@ def test_no_gpu_fails_loudly(lib):
         pytest.skip("GPU present")
     with pytest.raises(capi.PrbError):
         capi.Context(0)
+
+
+def test_division_free_div100_is_exact(tmp_path):
+    """The device code's fused-multiply-add form of z / 100.0 equals the IEEE quotient for
+    every integer energy it can meet (|z| <= 100000)."""
+    import subprocess
+    exe = str(tmp_path / "div100_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "div100_check.c")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == "0"
