@@ -692,7 +692,9 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
 
   // ---- ungapped extension, sort, redundancy filter ----
   if ((rc = ctx->time_begin())) return rc;
-  PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, ctx->stream));
+  int max_qlen = 0;
+  for (int32_t q = 0; q < qb->nq; q++) max_qlen = std::max(max_qlen, qb->len[q]);
+  PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, max_qlen, ctx->stream));
   if ((rc = ctx->time_end("ungapped", 1))) return rc;
   // hits above the -f threshold are dropped before the sort (they cannot survive the filter)
   if ((rc = w.hitsB.ensure(hits_bytes(nseed)))) return rc;

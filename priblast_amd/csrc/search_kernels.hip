@@ -112,79 +112,198 @@ __device__ __forceinline__ double loop_energy_ungapped(const SearchConst &sc, in
   return div100(sc, z);
 }
 
-__global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatchDev qb, PageDev pg, SearchConst sc,
-                                                     ExtOpts o) {
-  const int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (x >= n) return;
-  const int query = h.query[x];
-  const int64_t qo = qb.off[query];
-  const uint8_t *qs = qb.enc + qo;
-  const float *qacc = qb.acc + qo, *qcond = qb.cond + qo;
+// The tables UngappedExtension::LoopEnergy reads: all but the 2x2 table (160 KB, one pair in ten)
+// are staged in LDS by the workgroup.
+struct UngappedTabs {
+  const int32_t *stack37, *internal37, *mismatchI37, *int11; // LDS
+  const int32_t *int22;                                        // HBM / L2
+};
+constexpr int kUtStack = 0, kUtInternal = 49, kUtMismatch = 49 + 31, kUtInt11 = 49 + 31 + 175, kUtTotal = 49 + 31 + 175 + 1600;
+
+// UngappedExtension::LoopEnergy (ungapped_extension.cpp:157-186) on values the walk already holds:
+// the loop between the pairs (type, type2) is symmetric, u unpaired bases per strand; a, b = the
+// bases next to the first pair (query, db), c, d = next to the second one.
+__device__ __forceinline__ double loop_energy_ungapped_abcd(const SearchConst &sc, const UngappedTabs &t, int type, int type2,
+                                                           int u, int a, int b, int c, int d) {
+  int z;
+  if (u == 0) z = t.stack37[type * 7 + type2];
+  else if (u == 1) z = t.int11[((type * 8 + type2) * 5 + a) * 5 + b];
+  else if (u == 2) z = t.int22[((((type * 8 + type2) * 5 + a) * 5 + c) * 5 + d) * 5 + b];
+  else z = t.internal37[2 * u] + t.mismatchI37[(type * 5 + a) * 5 + b] + t.mismatchI37[(type2 * 5 + d) * 5 + c];
+  return div100(sc, z);
+}
+
+// The query side of a walk: in HBM, or staged in LDS by the workgroup.
+struct QueryGlobal {
+  const uint8_t *qs;
+  const float *qacc, *qcond;
+  __device__ __forceinline__ unsigned enc(int i) const { return qs[i]; }
+  __device__ __forceinline__ float acc(int i) const { return qacc[i]; }
+  __device__ __forceinline__ float cond(int i) const { return qcond[i]; }
+};
+struct QueryLds {
+  const uint8_t *qs; // derived from the kernel's __shared__ block
+  const float *qacc, *qcond;
+  __device__ __forceinline__ unsigned enc(int i) const { return qs[i]; }
+  __device__ __forceinline__ float acc(int i) const { return qacc[i]; }
+  __device__ __forceinline__ float cond(int i) const { return qcond[i]; }
+};
+
+// One seed hit (UngappedExtension::Run, ungapped_extension.cpp:30-155).  A walk is a chain of
+// data-dependent steps, and what it costs is memory latency, not arithmetic (PMC: VALU 16 % busy,
+// ~400 ns per load, all exposed).  So: the query side and the small energy tables come from LDS;
+// the database side of the next kUngappedAhead positions is fetched at once, speculatively
+// (clamped to the arrays; a walk that stops earlier just drops the values); and everything a step
+// needs again later is carried in registers - the accessibility of the previous position, the
+// bases of the previous position and of the position next to the last pair, the type of the
+// last pair (the reference re-reads all of them).
+constexpr int kUngappedAhead = 8;
+template <class Q>
+__device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &tabs, HitSoA &h, int64_t x, const PageDev &pg,
+                                              const SearchConst &sc, const ExtOpts &o) {
   const uint8_t *ds = pg.seqs;
   const int id = h.db_id[x];
   const int64_t base = (int64_t)pg.start_pos[id] - id;
-  const float *dacc = pg.acc + base, *dcond = pg.cond + base;
+  const int64_t nacc = (int64_t)pg.nchars - pg.nseq; // floats in pg.acc / pg.cond
   const int delta = o.delta, drop = o.drop_wo_gap;
   const int q_sp0 = h.q_sp[x], db_sp0 = h.db_sp[x], len0 = h.q_len[x];
 
   double min_e = h.e_tot[x], e = min_e, min_a = h.e_acc[x], a = min_a, min_h = h.e_hyb[x], hy = min_h;
-  int i = q_sp0, p = q_sp0, j = db_sp0, q = db_sp0, min_p = p, min_q = q;
+  int i = q_sp0, p = q_sp0, j = db_sp0, min_p = p, min_q = db_sp0;
   int id_start = h.db_id_start[x], id_end = id_start + len0 - 1, min_id_start = id_start;
-  for (;;) { // walk left (ungapped_extension.cpp:55-94)
-    i--;
-    j--;
-    id_end++;
-    if (i < 0 || j < 0 || qs[i] < 2 || ds[j] < 2) break;
-    const double ta = qacc[i] - qacc[i + 1] + qcond[i + delta] + dcond[id_end]; // float arithmetic, as the reference
-    e += ta;
-    a += ta;
-    const int type = bp_type(sc, base_of(qs[i]), base_of(ds[j]));
-    if (type != 0) {
-      const int type2 = rtype_of(bp_type(sc, base_of(qs[p]), base_of(ds[q])));
-      const double le = loop_energy_ungapped(sc, type, type2, i, j, p, q, qs, ds);
-      e += le;
-      hy += le;
-      if (e < min_e) {
-        min_e = e;
-        min_a = a;
-        min_h = hy;
-        min_p = i;
-        min_q = j;
+  {
+    // walk left (:55-94).  (bq, bd) = bases at (i+1, j+1); (cq, cd) = bases at (p-1, q-1), the
+    // position next to the last pair; tp = rtype of the pair at (p, q)
+    int bq = base_of(qv.enc(i)), bd = base_of(ds[j]);
+    int tp = rtype_of(bp_type(sc, bq, bd));
+    int cq = 0, cd = 0;
+    float acc_next = qv.acc(i); // qacc[i + 1] of the step to come
+    bool done = false;
+    while (!done) {
+      unsigned dcs[kUngappedAhead];
+      float dcn[kUngappedAhead];
+#pragma unroll
+      for (int s = 0; s < kUngappedAhead; s++) {
+        const int jj = j - 1 - s;
+        dcs[s] = jj >= 0 ? ds[jj] : 0u;
+        int64_t ci = base + id_end + 1 + s;
+        ci = ci < nacc ? ci : nacc - 1;
+        dcn[s] = pg.cond[ci];
       }
-      p = i;
-      q = j;
+#pragma unroll
+      for (int s = 0; s < kUngappedAhead; s++) {
+        if (done) continue;
+        i--;
+        j--;
+        id_end++;
+        if (i < 0 || j < 0) {
+          done = true;
+          continue;
+        }
+        const unsigned qc = qv.enc(i), dc = dcs[s];
+        if (qc < 2 || dc < 2) {
+          done = true;
+          continue;
+        }
+        const float acc_i = qv.acc(i);
+        const double ta = acc_i - acc_next + qv.cond(i + delta) + dcn[s]; // float arithmetic, as the reference
+        acc_next = acc_i;
+        e += ta;
+        a += ta;
+        const int nq = base_of(qc), nd = base_of(dc);
+        if (i == p - 1) {
+          cq = nq;
+          cd = nd;
+        }
+        const int type = bp_type(sc, nq, nd);
+        if (type != 0) {
+          const double le = loop_energy_ungapped_abcd(sc, tabs, type, tp, p - i - 1, bq, bd, cq, cd);
+          e += le;
+          hy += le;
+          if (e < min_e) {
+            min_e = e;
+            min_a = a;
+            min_h = hy;
+            min_p = i;
+            min_q = j;
+          }
+          p = i;
+          tp = rtype_of(type);
+        }
+        bq = nq;
+        bd = nd;
+        if (min_p - i >= drop) done = true;
+      }
     }
-    if (min_p - i >= drop) break;
   }
   e = min_e;
   a = min_a;
   hy = min_h;
-  int k = q_sp0 + len0 - 1, r = k, l = db_sp0 + len0 - 1, s = l, min_r = r;
-  for (;;) { // walk right (:96-145)
-    k++;
-    l++;
-    id_start--;
-    if (qs[k] < 2 || ds[l] < 2) break;
-    const double ta = qcond[k] + dacc[id_start] - dacc[id_start + 1] + dcond[id_start + delta];
-    e += ta;
-    a += ta;
-    const int type2 = rtype_of(bp_type(sc, base_of(qs[k]), base_of(ds[l])));
-    if (type2 != 0) {
-      const int type = bp_type(sc, base_of(qs[r]), base_of(ds[s]));
-      const double le = loop_energy_ungapped(sc, type, type2, r, s, k, l, qs, ds);
-      e += le;
-      hy += le;
-      if (e < min_e) {
-        min_e = e;
-        min_a = a;
-        min_h = hy;
-        min_r = k;
-        min_id_start = id_start;
+  int k = q_sp0 + len0 - 1, r = k, l = db_sp0 + len0 - 1, min_r = r;
+  {
+    // walk right (:96-145).  (bq, bd) = bases at (k-1, l-1); (cq, cd) = bases at (r+1, s+1); tr = type
+    // of the pair at (r, s)
+    int bq = base_of(qv.enc(k)), bd = base_of(ds[l]);
+    int tr = bp_type(sc, bq, bd);
+    int cq = 0, cd = 0;
+    float acc_prev = pg.acc[base + id_start]; // dacc[id_start + 1] of the step to come
+    bool done = false;
+    while (!done) {
+      unsigned dcs[kUngappedAhead];
+      float dan[kUngappedAhead], dcn[kUngappedAhead];
+#pragma unroll
+      for (int s = 0; s < kUngappedAhead; s++) {
+        const int ll = l + 1 + s;
+        dcs[s] = ll < pg.nchars ? ds[ll] : 0u;
+        int64_t ai = base + id_start - 1 - s;
+        ai = ai > 0 ? ai : 0;
+        int64_t ci = ai + delta;
+        ci = ci < nacc ? ci : nacc - 1;
+        dan[s] = pg.acc[ai];
+        dcn[s] = pg.cond[ci];
       }
-      r = k;
-      s = l;
+#pragma unroll
+      for (int s = 0; s < kUngappedAhead; s++) {
+        if (done) continue;
+        k++;
+        l++;
+        id_start--;
+        const unsigned qc = qv.enc(k), dc = dcs[s];
+        if (qc < 2 || dc < 2) {
+          done = true;
+          continue;
+        }
+        const float acc_i = dan[s];
+        const double ta = qv.cond(k) + acc_i - acc_prev + dcn[s];
+        acc_prev = acc_i;
+        e += ta;
+        a += ta;
+        const int nq = base_of(qc), nd = base_of(dc);
+        if (k == r + 1) {
+          cq = nq;
+          cd = nd;
+        }
+        const int type2 = rtype_of(bp_type(sc, nq, nd));
+        if (type2 != 0) {
+          // loop between (r, s) and (k, l): a, b next to the first pair, c, d next to the second
+          const double le = loop_energy_ungapped_abcd(sc, tabs, tr, type2, k - r - 1, cq, cd, bq, bd);
+          e += le;
+          hy += le;
+          if (e < min_e) {
+            min_e = e;
+            min_a = a;
+            min_h = hy;
+            min_r = k;
+            min_id_start = id_start;
+          }
+          r = k;
+          tr = rtype_of(type2);
+        }
+        bq = nq;
+        bd = nd;
+        if (k - min_r >= drop) done = true;
+      }
     }
-    if (k - min_r >= drop) break;
   }
   h.db_id_start[x] = min_id_start;
   h.q_sp[x] = min_p;
@@ -194,6 +313,51 @@ __global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatch
   h.e_tot[x] = min_e;
   h.e_acc[x] = min_a;
   h.e_hyb[x] = min_h;
+}
+
+// A workgroup takes kUngappedPer x kBlock consecutive seed hits.  Seed hits are emitted query
+// by query, and the 64 lanes of a wave sit at 64 unrelated positions of that query (its suffix-array
+// interval) but at one position of the database.  When all hits of the workgroup belong to one
+// query (all but the few workgroups at query boundaries), the query's codes and accessibilities
+// (9 B per nucleotide) are staged in LDS; queries longer than the launch's LDS capacity take the
+// HBM path.
+constexpr int kUngappedPer = 8;
+__global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatchDev qb, PageDev pg, SearchConst sc, ExtOpts o,
+                                                     int qcap) {
+  extern __shared__ __align__(16) uint8_t ungapped_smem[];
+  __shared__ int32_t s_tab[kUtTotal];
+  const int64_t b0 = (int64_t)blockIdx.x * (kBlock * kUngappedPer);
+  if (b0 >= n) return;
+  const int64_t b1 = (b0 + kBlock * kUngappedPer < n ? b0 + kBlock * kUngappedPer : n) - 1;
+  for (int t = threadIdx.x; t < kUtTotal; t += kBlock)
+    s_tab[t] = t < kUtInternal   ? sc.stack37[t]
+               : t < kUtMismatch ? sc.internal37[t - kUtInternal]
+               : t < kUtInt11    ? sc.mismatchI37[t - kUtMismatch]
+                                 : sc.int11[t - kUtInt11];
+  const UngappedTabs tabs{s_tab + kUtStack, s_tab + kUtInternal, s_tab + kUtMismatch, s_tab + kUtInt11, sc.int22};
+  const int q0 = h.query[b0];
+  const int nslots = qb.len[q0] + 1;
+  const bool staged = q0 == h.query[b1] && nslots <= qcap; // uniform over the workgroup
+  if (staged) {
+    float *s_acc = reinterpret_cast<float *>(ungapped_smem), *s_cond = s_acc + qcap;
+    uint8_t *s_enc = reinterpret_cast<uint8_t *>(s_cond + qcap);
+    const int64_t qo = qb.off[q0];
+    for (int t = threadIdx.x; t < nslots; t += kBlock) {
+      s_acc[t] = qb.acc[qo + t];
+      s_cond[t] = qb.cond[qo + t];
+      s_enc[t] = qb.enc[qo + t];
+    }
+    __syncthreads();
+    const QueryLds qv{s_enc, s_acc, s_cond};
+    for (int64_t x = b0 + threadIdx.x; x <= b1; x += kBlock) ungapped_walk(qv, tabs, h, x, pg, sc, o);
+  } else {
+    __syncthreads();
+    for (int64_t x = b0 + threadIdx.x; x <= b1; x += kBlock) {
+      const int64_t qo = qb.off[h.query[x]];
+      const QueryGlobal qv{qb.enc + qo, qb.acc + qo, qb.cond + qo};
+      ungapped_walk(qv, tabs, h, x, pg, sc, o);
+    }
+  }
 }
 
 // ------------------------------------------------------------------- sort keys / gather
@@ -385,9 +549,14 @@ hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, 
   return hipGetLastError();
 }
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc, ExtOpts o,
-                           hipStream_t s) {
+                           int max_query_len, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_ungapped, grid_for(n), dim3(kBlock), 0, s, hits, n, qb, pg, sc, o);
+  // LDS slots per query array: the longest query of the batch, at most 7168 (63 KB per workgroup)
+  int qcap = (max_query_len + 1 + 3) & ~3;
+  if (qcap > 7168) qcap = 7168;
+  const int64_t per_block = (int64_t)kBlock * kUngappedPer;
+  hipLaunchKernelGGL(k_ungapped, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), (size_t)qcap * 9, s, hits, n,
+                     qb, pg, sc, o, qcap);
   return hipGetLastError();
 }
 hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, uint32_t *k_len, uint32_t *k_qsp,

@@ -90,7 +90,7 @@ hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, 
                             const PageDev &pg, int delta, const int64_t *row_off, HitSoA hits, hipStream_t s);
 // ---- ungapped ----
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc,
-                           ExtOpts o, hipStream_t s);
+                           ExtOpts o, int max_query_len, hipStream_t s);
 // ---- sort keys / gather ----
 hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, uint32_t *k_len, uint32_t *k_qsp,
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s);
