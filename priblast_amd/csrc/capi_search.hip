@@ -3,6 +3,9 @@
 #include <omp.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -67,13 +70,95 @@ struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
       scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed;
-  PinnedBuf pinned;
+  PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
                       &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed})
       b->release();
     pinned.release();
+    cand_pinned.release();
+    for (int i = 0; i < 2; i++) {
+      pin_hits[i].release();
+      pin_bp[i].release();
+    }
+  }
+};
+
+// Appends the results of finished sub-batches (pinned staging slots filled by asynchronous
+// copies on the compute stream) to the hit set while the GPU already works on the next one.
+struct Drainer {
+  struct Job {
+    int slot;
+    int64_t nhits, nbp_ints;
+  };
+  std::vector<prb_hit> *hits;
+  std::vector<int32_t> *bp;
+  PinnedBuf *pin_hits, *pin_bp; // [2]
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Job> jobs;
+  bool busy[2] = {false, false}, stop = false, failed = false;
+
+  Drainer(std::vector<prb_hit> *h, std::vector<int32_t> *b, PinnedBuf *ph, PinnedBuf *pb)
+      : hits(h), bp(b), pin_hits(ph), pin_bp(pb) {}
+  int start() {
+    for (int i = 0; i < 2; i++)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return PRB_ERR_HIP;
+    th = std::thread([this] { run(); });
+    return PRB_OK;
+  }
+  void run() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return stop || !jobs.empty(); });
+        if (jobs.empty()) return;
+        j = jobs.front();
+        jobs.pop_front();
+      }
+      if (hipEventSynchronize(ev[j.slot]) != hipSuccess) failed = true;
+      const prb_hit *src = static_cast<const prb_hit *>(pin_hits[j.slot].p);
+      if (hits->capacity() < hits->size() + (size_t)j.nhits)
+        hits->reserve(std::max(2 * hits->capacity(), hits->size() + (size_t)j.nhits));
+      hits->insert(hits->end(), src, src + j.nhits);
+      const int32_t *bsrc = static_cast<const int32_t *>(pin_bp[j.slot].p);
+      if (bp->capacity() < bp->size() + (size_t)j.nbp_ints)
+        bp->reserve(std::max(2 * bp->capacity(), bp->size() + (size_t)j.nbp_ints));
+      bp->insert(bp->end(), bsrc, bsrc + j.nbp_ints);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        busy[j.slot] = false;
+      }
+      cv.notify_all();
+    }
+  }
+  // blocks until the staging slot is no longer read by the background thread
+  void acquire(int slot) {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return !busy[slot]; });
+    busy[slot] = true;
+  }
+  void submit(const Job &j) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      jobs.push_back(j);
+    }
+    cv.notify_all();
+  }
+  int finish() { // everything submitted is in the hit set afterwards
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+    for (int i = 0; i < 2; i++)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    return failed ? PRB_ERR_HIP : PRB_OK;
   }
 };
 
@@ -134,11 +219,19 @@ struct prb_qbatch {
   QBatchDev view{};
 };
 
+namespace prb {
+struct Drainer;
+}
 struct prb_hitset {
   std::vector<prb_hit> hits;
   std::vector<int32_t> bp;
   int64_t counts[3] = {0, 0, 0};
   int64_t slow_hits = 0; // extensions that outgrew the LDS kernel
+  // while prb_search_page runs: results of finished sub-batches are appended by a background
+  // thread; the main thread only keeps the totals it needs for the offsets
+  prb::Drainer *drain = nullptr;
+  int64_t hits_total = 0, bp_ints_total = 0;
+  int next_slot = 0;
 };
 
 namespace prb {
@@ -629,7 +722,7 @@ static int download_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, 
   int rc;
   const size_t bytes = (size_t)n * sizeof(prb_hit);
   if ((rc = w.packed.ensure(bytes)) || (rc = w.pinned.ensure(bytes))) return rc;
-  PRB_HIP(launch_pack_hits(h, n, w.packed.p, ctx->stream));
+  PRB_HIP(launch_pack_hits(h, n, nullptr, nullptr, -1, w.packed.p, ctx->stream));
   PRB_HIP(hipMemcpyAsync(w.pinned.p, w.packed.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (out.capacity() < base + (size_t)n) out.reserve(std::max(2 * out.capacity(), base + (size_t)n));
   PRB_HIP(hipStreamSynchronize(ctx->stream));
@@ -639,8 +732,10 @@ static int download_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, 
 }
 
 // all stages for the queries [q0, q1) of the batch against one page
+// One sub-batch of queries through the GPU stages.  cd (pinned host memory) = its seed candidates in
+// query order, row0 filled in; nrows = their database SA entries in total.
 static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, const prb_ris_opts &opts, int last_stage,
-                        const std::vector<SeedCandidate> &cands_all, size_t c0, size_t c1, prb_hitset *hs) {
+                        const CandDev *cd, int64_t ncand64, int64_t nrows, prb_hitset *hs) {
   SearchWs &w = ws_of(ctx);
   const SearchConst &sc = static_cast<SearchConstMem *>(ctx->search_const)->view;
   const DbPage &pg = db->pages[page];
@@ -649,19 +744,16 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   ExtOpts eo{delta, opts.drop_out_wo_gap, opts.drop_out_w_gap, opts.min_helix_length};
   int rc;
   // ---- seeds: one row per (candidate, db SA entry) ----
-  const int32_t ncand = (int32_t)(c1 - c0);
-  if (ncand == 0) return PRB_OK;
-  std::vector<CandDev> cd((size_t)ncand);
-  int64_t nrows = 0;
-  for (int32_t i = 0; i < ncand; i++) {
-    const SeedCandidate &s = cands_all[c0 + i];
-    cd[i] = CandDev{s.sp_q, s.ep_q, s.sp_db, s.ep_db, s.length, s.query, s.score, nrows};
-    nrows += (int64_t)s.ep_db - s.sp_db + 1;
+  if (ncand64 == 0) return PRB_OK;
+  if (ncand64 > INT32_MAX) {
+    set_error("too many seed candidates in one sub-batch: lower PRB_SEARCH_PAIRS");
+    return PRB_ERR_NOMEM;
   }
-  if ((rc = w.cands.ensure(cd.size() * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(nrows + 1) * 4)) ||
+  const int32_t ncand = (int32_t)ncand64;
+  if ((rc = w.cands.ensure((size_t)ncand * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(nrows + 1) * 4)) ||
       (rc = w.row_off.ensure((size_t)(nrows + 1) * 8)))
     return rc;
-  PRB_HIP(hipMemcpyAsync(w.cands.p, cd.data(), cd.size() * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
+  PRB_HIP(hipMemcpyAsync(w.cands.p, cd, (size_t)ncand * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
   if ((rc = ctx->time_begin())) return rc;
   // one extra zero entry so that the exclusive scan over nrows+1 values also yields the total
   PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + nrows, 0, 4, ctx->stream));
@@ -872,8 +964,6 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = w.subset2.ensure((size_t)nfin * 4))) return rc;
   PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset2.as<uint32_t>(), nfin, ctx->stream));
   PRB_HIP(launch_gather_u32(w.cidx.as<uint32_t>(), w.subset2.as<uint32_t>(), w.subset.as<uint32_t>(), nfin, ctx->stream));
-  const size_t base = hs->hits.size();
-  if ((rc = download_hits(ctx, w, F, nfin, hs->hits))) return rc;
 
   // ---- base pairs of the survivors: from the trace slots of the extension pass; the few hits
   // the slots cannot describe (wave-kernel hits, chains longer than a slot) are extended again ----
@@ -941,27 +1031,34 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = ctx->time_end("traceback_slow", 0))) return rc;
       if ((rc = ctx->time_begin())) return rc;
     }
-    const size_t bp_base = hs->bp.size();
+    // results: records packed on the device (with their base-pair ranges), one asynchronous copy
+    // each for hits and pairs into a pinned slot; the background thread appends them to the hit set
+    const int slot = hs->next_slot;
+    hs->next_slot ^= 1;
+    hs->drain->acquire(slot);
+    const int64_t bp_base_pairs = hs->bp_ints_total / 2;
+    const int64_t nbp_ints = opts.output_style == 0 ? nfin * 4 : total * 2;
+    if ((rc = w.packed.ensure((size_t)nfin * sizeof(prb_hit))) || (rc = w.pin_hits[slot].ensure((size_t)nfin * sizeof(prb_hit))) ||
+        (rc = w.pin_bp[slot].ensure((size_t)std::max<int64_t>(nbp_ints, 1) * 4)))
+      return rc;
+    const int32_t *bp_src;
     if (opts.output_style == 0) {
       // simplified output: only the first and the last pair of a hit are ever printed
       if ((rc = w.bpEnds.ensure((size_t)nfin * 16))) return rc;
       PRB_HIP(launch_bp_ends(w.bpOff.as<int64_t>(), nfin, w.bpOut.as<int32_t>(), w.bpEnds.as<int32_t>(), ctx->stream));
-      hs->bp.resize(bp_base + (size_t)nfin * 4);
-      PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpEnds.p, (size_t)nfin * 16, hipMemcpyDeviceToHost, ctx->stream));
-      PRB_HIP(hipStreamSynchronize(ctx->stream));
-      for (int64_t i = 0; i < nfin; i++) {
-        hs->hits[base + i].bp_count = 2;
-        hs->hits[base + i].bp_offset = (int64_t)(bp_base / 2) + 2 * i;
-      }
+      PRB_HIP(launch_pack_hits(F, nfin, nullptr, nullptr, bp_base_pairs, w.packed.p, ctx->stream));
+      bp_src = w.bpEnds.as<int32_t>();
     } else {
-      hs->bp.resize(bp_base + (size_t)total * 2);
-      if (total) PRB_HIP(hipMemcpyAsync(hs->bp.data() + bp_base, w.bpOut.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-      PRB_HIP(hipStreamSynchronize(ctx->stream));
-      for (int64_t i = 0; i < nfin; i++) {
-        hs->hits[base + i].bp_count = cnt[i];
-        hs->hits[base + i].bp_offset = (int64_t)(bp_base / 2) + off[i];
-      }
+      PRB_HIP(launch_pack_hits(F, nfin, w.bpCount.as<int32_t>(), w.bpOff.as<int64_t>(), bp_base_pairs, w.packed.p, ctx->stream));
+      bp_src = w.bpOut.as<int32_t>();
     }
+    PRB_HIP(hipMemcpyAsync(w.pin_hits[slot].p, w.packed.p, (size_t)nfin * sizeof(prb_hit), hipMemcpyDeviceToHost, ctx->stream));
+    if (nbp_ints)
+      PRB_HIP(hipMemcpyAsync(w.pin_bp[slot].p, bp_src, (size_t)nbp_ints * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipEventRecord(hs->drain->ev[slot], ctx->stream));
+    hs->drain->submit(Drainer::Job{slot, nfin, nbp_ints});
+    hs->hits_total += nfin;
+    hs->bp_ints_total += nbp_ints;
   }
   return ctx->time_end("traceback", 2);
 }
@@ -1000,21 +1097,28 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   const int32_t nq = qb->nq;
   std::vector<std::vector<SeedCandidate>> per_q((size_t)nq);
   std::vector<double> qpairs((size_t)nq, 0);
+  std::vector<int64_t> qrows((size_t)nq, 0);
   std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[(size_t)nq]);
   for (int32_t q = 0; q < nq; q++) done[q].store(0, std::memory_order_relaxed);
   const auto t_dfs0 = std::chrono::steady_clock::now();
   double dfs_ms = 0;
+  std::atomic<int32_t> next_query{0}; // queries are handed out strictly in order: the consumer needs the first ones first
   std::thread producer([&] {
-#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads(nq))
-    for (int32_t q = 0; q < nq; q++) {
+#pragma omp parallel num_threads(host_threads(nq))
+    for (;;) {
+      const int32_t q = next_query.fetch_add(1, std::memory_order_relaxed);
+      if (q >= nq) break;
       seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
                opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
       double pairs = 0;
+      int64_t rows = 0;
       for (auto &c : per_q[q]) {
         c.query = q;
         pairs += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
+        rows += (int64_t)c.ep_db - c.sp_db + 1;
       }
       qpairs[q] = pairs;
+      qrows[q] = rows;
       done[q].store(1, std::memory_order_release);
     }
     dfs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dfs0).count();
@@ -1023,33 +1127,67 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     while (!done[q].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
   };
   auto *hs = new prb_hitset();
+  SearchWs &wsp = ws_of(ctx);
+  Drainer drain(&hs->hits, &hs->bp, wsp.pin_hits, wsp.pin_bp);
+  hs->drain = &drain;
   const char *env = getenv("PRB_SEARCH_PAIRS");
   const double budget = env ? atof(env) : 1.2e8;
-  int rc = PRB_OK;
-  std::vector<SeedCandidate> cands;
+  int rc = drain.start();
   double wait_ms = 0;
+  std::vector<int64_t> cbase, rbase;
   for (int32_t q0 = 0; q0 < nq && rc == PRB_OK;) {
     const auto tw0 = std::chrono::steady_clock::now();
     int32_t q1 = q0;
     double acc = 0;
-    cands.clear();
     for (;;) { // queries [q0, q1) of this sub-batch: as many as fit the pair budget
       if (q1 >= nq) break;
       wait_for(q1);
       if (q1 > q0 && acc + qpairs[q1] > budget) break;
       acc += qpairs[q1];
-      cands.insert(cands.end(), per_q[q1].begin(), per_q[q1].end());
-      std::vector<SeedCandidate>().swap(per_q[q1]);
       q1++;
     }
     wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+    // the sub-batch's candidates, converted straight into pinned memory (queries in parallel)
+    const int32_t nb = q1 - q0;
+    cbase.assign((size_t)nb + 1, 0);
+    rbase.assign((size_t)nb + 1, 0);
+    for (int32_t k = 0; k < nb; k++) {
+      cbase[k + 1] = cbase[k] + (int64_t)per_q[q0 + k].size();
+      rbase[k + 1] = rbase[k] + qrows[q0 + k];
+    }
+    const int64_t ncand = cbase[nb], nrows = rbase[nb];
+    if ((rc = wsp.cand_pinned.ensure((size_t)std::max<int64_t>(ncand, 1) * sizeof(CandDev)))) break;
+    CandDev *cd = static_cast<CandDev *>(wsp.cand_pinned.p);
+    {
+      HostTimer ht(ctx, "host_cands");
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(8, host_threads(nb)))
+      for (int32_t k = 0; k < nb; k++) {
+        std::vector<SeedCandidate> &v = per_q[q0 + k];
+        CandDev *out = cd + cbase[k];
+        int64_t row = rbase[k];
+        for (size_t i = 0; i < v.size(); i++) {
+          const SeedCandidate &c = v[i];
+          out[i] = CandDev{c.sp_q, c.ep_q, c.sp_db, c.ep_db, c.length, c.query, c.score, row};
+          row += (int64_t)c.ep_db - c.sp_db + 1;
+        }
+        std::vector<SeedCandidate>().swap(v);
+      }
+    }
     {
       HostTimer ht(ctx, "host_search_range");
-      rc = search_range(ctx, qb, db, page, *opts, last_stage, cands, 0, cands.size(), hs);
+      rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, hs);
     }
+    // the pinned candidates are reused by the next sub-batch: their upload must be over
+    if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;
     q0 = q1;
   }
   producer.join();
+  {
+    HostTimer ht(ctx, "host_drain_tail");
+    const int drc = drain.finish();
+    if (rc == PRB_OK) rc = drc;
+    hs->drain = nullptr;
+  }
   ctx->timers["host_dfs"].ms += dfs_ms;       // wall time of the background DFS
   ctx->timers["host_dfs"].launches++;
   ctx->timers["host_dfs_wait"].ms += wait_ms; // what the GPU pipeline actually waited for it

@@ -397,8 +397,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_hits(HitSoA s, const uint32_t
   d.e_tot[i] = s.e_tot[j];
 }
 
-// SoA hits -> the C ABI's records (include/priblast_hip.h), so that one copy brings them to the host
-__global__ __launch_bounds__(kBlock) void k_pack_hits(HitSoA s, int64_t n, prb_hit *out) {
+// SoA hits -> the C ABI's records (include/priblast_hip.h), so that one copy brings them to the host.
+// bp_base >= 0: the records also get their range in the hit set's base-pair array: hit i has
+// bp_count[i] pairs from pair index bp_base + bp_off[i] on (no arrays: the two end pairs, 2 per hit).
+__global__ __launch_bounds__(kBlock) void k_pack_hits(HitSoA s, int64_t n, const int32_t *__restrict__ bp_count,
+                                                      const int64_t *__restrict__ bp_off, int64_t bp_base, prb_hit *out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   prb_hit h;
@@ -412,8 +415,8 @@ __global__ __launch_bounds__(kBlock) void k_pack_hits(HitSoA s, int64_t n, prb_h
   h.e_hyb = s.e_hyb[i];
   h.e_tot = s.e_tot[i];
   h.query = s.query[i];
-  h.bp_count = 0;
-  h.bp_offset = 0;
+  h.bp_count = bp_base < 0 ? 0 : bp_count ? bp_count[i] : 2;
+  h.bp_offset = bp_base < 0 ? 0 : bp_base + (bp_off ? bp_off[i] : 2 * i);
   out[i] = h;
 }
 
@@ -585,9 +588,10 @@ hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst
   hipLaunchKernelGGL(k_gather_hits, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
   return hipGetLastError();
 }
-hipError_t launch_pack_hits(const HitSoA &src, int64_t n, void *out, hipStream_t s) {
+hipError_t launch_pack_hits(const HitSoA &src, int64_t n, const int32_t *bp_count, const int64_t *bp_off, int64_t bp_base,
+                            void *out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_pack_hits, grid_for(n), dim3(kBlock), 0, s, src, n, static_cast<prb_hit *>(out));
+  hipLaunchKernelGGL(k_pack_hits, grid_for(n), dim3(kBlock), 0, s, src, n, bp_count, bp_off, bp_base, static_cast<prb_hit *>(out));
   return hipGetLastError();
 }
 hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s) {

@@ -96,8 +96,10 @@ hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, u
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s);
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t *dst, int64_t n, hipStream_t s);
-// out: n records of prb_hit (include/priblast_hip.h) in device memory
-hipError_t launch_pack_hits(const HitSoA &src, int64_t n, void *out, hipStream_t s);
+// out: n records of prb_hit (include/priblast_hip.h) in device memory; bp_base >= 0 also fills their
+// base-pair ranges (bp_count / bp_off per hit, or 2 pairs per hit when those are null)
+hipError_t launch_pack_hits(const HitSoA &src, int64_t n, const int32_t *bp_count, const int64_t *bp_off, int64_t bp_base,
+                            void *out, hipStream_t s);
 hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
 hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s);
