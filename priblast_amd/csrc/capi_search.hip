@@ -36,7 +36,7 @@ struct SearchConstMem {
 };
 
 struct PageMem {
-  DevBuf seqs, sa, start_pos, seq_length, acc, cond;
+  DevBuf seqs, sa, sa_seq, start_pos, seq_length, acc, cond;
   PageDev view{};
 };
 
@@ -69,12 +69,12 @@ struct PinnedBuf {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc})
       b->release();
     pinned.release();
     cand_pinned.release();
@@ -345,15 +345,18 @@ static int upload_page(prb_ctx *ctx, const DbPage &pg, PageMem &m) {
   if ((rc = up(m.seq_length, pg.seq_length.data(), pg.seq_length.size() * 4))) return rc;
   if ((rc = up(m.acc, pg.acc.data(), pg.acc.size() * 4))) return rc;
   if ((rc = up(m.cond, pg.cond.data(), pg.cond.size() * 4))) return rc;
-  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  if ((rc = m.sa_seq.ensure(std::max<size_t>(pg.sa.size() * 4, 16)))) return rc;
   m.view.seqs = m.seqs.as<uint8_t>();
   m.view.sa = m.sa.as<int32_t>();
+  m.view.sa_seq = m.sa_seq.as<int32_t>();
   m.view.start_pos = m.start_pos.as<int32_t>();
   m.view.seq_length = m.seq_length.as<int32_t>();
   m.view.acc = m.acc.as<float>();
   m.view.cond = m.cond.as<float>();
   m.view.nchars = (int32_t)pg.seqs.size();
   m.view.nseq = pg.nseq;
+  PRB_HIP(launch_sa_seq(m.view, m.sa_seq.as<int32_t>(), ctx->stream));
+  PRB_HIP(hipStreamSynchronize(ctx->stream));
   return PRB_OK;
 }
 
@@ -384,7 +387,7 @@ int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
 void prb_db_close(prb_db *db) {
   if (!db) return;
   for (auto &m : db->mem)
-    for (DevBuf *b : {&m.seqs, &m.sa, &m.start_pos, &m.seq_length, &m.acc, &m.cond}) b->release();
+    for (DevBuf *b : {&m.seqs, &m.sa, &m.sa_seq, &m.start_pos, &m.seq_length, &m.acc, &m.cond}) b->release();
   delete db;
 }
 
@@ -735,7 +738,7 @@ static int download_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, 
 // One sub-batch of queries through the GPU stages.  cd (pinned host memory) = its seed candidates in
 // query order, row0 filled in; nrows = their database SA entries in total.
 static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, const prb_ris_opts &opts, int last_stage,
-                        const CandDev *cd, int64_t ncand64, int64_t nrows, prb_hitset *hs) {
+                        const CandDev *cd, int64_t ncand64, int64_t nrows, int64_t nqent, prb_hitset *hs) {
   SearchWs &w = ws_of(ctx);
   const SearchConst &sc = static_cast<SearchConstMem *>(ctx->search_const)->view;
   const DbPage &pg = db->pages[page];
@@ -751,13 +754,16 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   }
   const int32_t ncand = (int32_t)ncand64;
   if ((rc = w.cands.ensure((size_t)ncand * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(nrows + 1) * 4)) ||
-      (rc = w.row_off.ensure((size_t)(nrows + 1) * 8)))
+      (rc = w.row_off.ensure((size_t)(nrows + 1) * 8)) || (rc = w.row_cand.ensure((size_t)(nrows + 1) * 4)) ||
+      (rc = w.seed_qacc.ensure((size_t)std::max<int64_t>(nqent, 1) * 8)))
     return rc;
   PRB_HIP(hipMemcpyAsync(w.cands.p, cd, (size_t)ncand * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
   if ((rc = ctx->time_begin())) return rc;
   // one extra zero entry so that the exclusive scan over nrows+1 values also yields the total
   PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + nrows, 0, 4, ctx->stream));
-  PRB_HIP(launch_seed_count(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.row_count.as<int32_t>(), ctx->stream));
+  PRB_HIP(launch_seed_qacc(w.cands.as<CandDev>(), ncand, nqent, qb->view, delta, w.seed_qacc.as<double>(), ctx->stream));
+  PRB_HIP(launch_seed_count(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.seed_qacc.as<double>(),
+                            w.row_count.as<int32_t>(), w.row_cand.as<int32_t>(), ctx->stream));
   {
     size_t tmp = 0;
     auto in = rocprim::make_transform_iterator(w.row_count.as<int32_t>(), ToI64());
@@ -778,7 +784,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   }
   if ((rc = w.hitsA.ensure(hits_bytes(nseed)))) return rc;
   HitSoA A = carve_hits(w.hitsA, nseed);
-  PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.row_off.as<int64_t>(), A, ctx->stream));
+  PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.seed_qacc.as<double>(),
+                           w.row_cand.as<int32_t>(), w.row_off.as<int64_t>(), A, ctx->stream));
   if ((rc = ctx->time_end("seed", 2))) return rc;
   if (last_stage == 1) return download_hits(ctx, w, A, nseed, hs->hits);
 
@@ -1097,7 +1104,7 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   const int32_t nq = qb->nq;
   std::vector<std::vector<SeedCandidate>> per_q((size_t)nq);
   std::vector<double> qpairs((size_t)nq, 0);
-  std::vector<int64_t> qrows((size_t)nq, 0);
+  std::vector<int64_t> qrows((size_t)nq, 0), qents((size_t)nq, 0);
   std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[(size_t)nq]);
   for (int32_t q = 0; q < nq; q++) done[q].store(0, std::memory_order_relaxed);
   const auto t_dfs0 = std::chrono::steady_clock::now();
@@ -1111,14 +1118,16 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
       seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
                opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
       double pairs = 0;
-      int64_t rows = 0;
+      int64_t rows = 0, ents = 0;
       for (auto &c : per_q[q]) {
         c.query = q;
         pairs += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
         rows += (int64_t)c.ep_db - c.sp_db + 1;
+        ents += (int64_t)c.ep_q - c.sp_q + 1;
       }
       qpairs[q] = pairs;
       qrows[q] = rows;
+      qents[q] = ents;
       done[q].store(1, std::memory_order_release);
     }
     dfs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dfs0).count();
@@ -1134,7 +1143,7 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   const double budget = env ? atof(env) : 1.2e8;
   int rc = drain.start();
   double wait_ms = 0;
-  std::vector<int64_t> cbase, rbase;
+  std::vector<int64_t> cbase, rbase, ebase;
   for (int32_t q0 = 0; q0 < nq && rc == PRB_OK;) {
     const auto tw0 = std::chrono::steady_clock::now();
     int32_t q1 = q0;
@@ -1151,11 +1160,13 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     const int32_t nb = q1 - q0;
     cbase.assign((size_t)nb + 1, 0);
     rbase.assign((size_t)nb + 1, 0);
+    ebase.assign((size_t)nb + 1, 0);
     for (int32_t k = 0; k < nb; k++) {
       cbase[k + 1] = cbase[k] + (int64_t)per_q[q0 + k].size();
       rbase[k + 1] = rbase[k] + qrows[q0 + k];
+      ebase[k + 1] = ebase[k] + qents[q0 + k];
     }
-    const int64_t ncand = cbase[nb], nrows = rbase[nb];
+    const int64_t ncand = cbase[nb], nrows = rbase[nb], nqent = ebase[nb];
     if ((rc = wsp.cand_pinned.ensure((size_t)std::max<int64_t>(ncand, 1) * sizeof(CandDev)))) break;
     CandDev *cd = static_cast<CandDev *>(wsp.cand_pinned.p);
     {
@@ -1164,18 +1175,19 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
       for (int32_t k = 0; k < nb; k++) {
         std::vector<SeedCandidate> &v = per_q[q0 + k];
         CandDev *out = cd + cbase[k];
-        int64_t row = rbase[k];
+        int64_t row = rbase[k], ent = ebase[k];
         for (size_t i = 0; i < v.size(); i++) {
           const SeedCandidate &c = v[i];
-          out[i] = CandDev{c.sp_q, c.ep_q, c.sp_db, c.ep_db, c.length, c.query, c.score, row};
+          out[i] = CandDev{c.sp_q, c.ep_q, c.sp_db, c.ep_db, c.length, c.query, c.score, row, ent};
           row += (int64_t)c.ep_db - c.sp_db + 1;
+          ent += (int64_t)c.ep_q - c.sp_q + 1;
         }
         std::vector<SeedCandidate>().swap(v);
       }
     }
     {
       HostTimer ht(ctx, "host_search_range");
-      rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, hs);
+      rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, nqent, hs);
     }
     // the pinned candidates are reused by the next sub-batch: their upload must be over
     if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;

@@ -75,37 +75,47 @@ struct Tier2 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgrou
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
-// ptype = Cell::type); the LDS form packs it into 32 bits, the HBM form into 64.
+// the bases at (i+1, j+1) that a later loop closing on this cell needs); Cell::type lives in the rotating
+// rows instead.  The LDS forms pack a record into 32 bits, the HBM form into 64.
 struct Rec32 {
-  using word = uint32_t; // i:7 | j:7 | pred:7 | type:3 | ptype:3
-  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
-    return (word)i | ((word)j << 7) | ((word)pred << 14) | ((word)type << 21) | ((word)ptype << 24);
+  using word = uint32_t; // i:7 | j:7 | pred:7 | type:3 | qa:3 | da:3 (the bases at (i+1, j+1) along the extension)
+  static constexpr bool kBases = true;
+  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int qa, int da) {
+    return (word)i | ((word)j << 7) | ((word)pred << 14) | ((word)type << 21) | ((word)qa << 24) | ((word)da << 27);
   }
   static __device__ __forceinline__ int i(word v) { return v & 0x7F; }
   static __device__ __forceinline__ int j(word v) { return (v >> 7) & 0x7F; }
   static __device__ __forceinline__ int pred(word v) { return (v >> 14) & 0x7F; }
   static __device__ __forceinline__ int type(word v) { return (v >> 21) & 7; }
+  static __device__ __forceinline__ int qa(word v) { return (v >> 24) & 7; }
+  static __device__ __forceinline__ int da(word v) { return (v >> 27) & 7; }
 };
-struct Rec32W { // tier 2
-  using word = uint32_t; // i:8 | j:8 | pred:9 | type:3 | ptype:3
-  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
-    return (word)i | ((word)j << 8) | ((word)pred << 16) | ((word)type << 25) | ((word)ptype << 28);
+struct Rec32W { // tier 2: no room for the neighbour bases, they are read from the staged windows
+  using word = uint32_t; // i:8 | j:8 | pred:9 | type:3
+  static constexpr bool kBases = false;
+  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int, int) {
+    return (word)i | ((word)j << 8) | ((word)pred << 16) | ((word)type << 25);
   }
   static __device__ __forceinline__ int i(word v) { return v & 0xFF; }
   static __device__ __forceinline__ int j(word v) { return (v >> 8) & 0xFF; }
   static __device__ __forceinline__ int pred(word v) { return (v >> 16) & 0x1FF; }
   static __device__ __forceinline__ int type(word v) { return (v >> 25) & 7; }
+  static __device__ __forceinline__ int qa(word) { return 0; }
+  static __device__ __forceinline__ int da(word) { return 0; }
 };
 struct Rec64 {
-  using word = uint64_t; // i:16 | j:16 | type:4 | ptype:4 | pred:24
-  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int ptype) {
-    return (word)(uint32_t)i | ((word)(uint32_t)j << 16) | ((word)type << 32) | ((word)ptype << 36) |
-           ((word)(uint32_t)pred << 40);
+  using word = uint64_t; // i:16 | j:16 | type:4 | qa:4 | da:4 | pred:20
+  static constexpr bool kBases = true;
+  static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int qa, int da) {
+    return (word)(uint32_t)i | ((word)(uint32_t)j << 16) | ((word)type << 32) | ((word)qa << 36) | ((word)da << 40) |
+           ((word)(uint32_t)pred << 44);
   }
   static __device__ __forceinline__ int i(word v) { return (int)(v & 0xFFFF); }
   static __device__ __forceinline__ int j(word v) { return (int)((v >> 16) & 0xFFFF); }
-  static __device__ __forceinline__ int pred(word v) { return (int)(v >> 40); }
+  static __device__ __forceinline__ int pred(word v) { return (int)(v >> 44); }
   static __device__ __forceinline__ int type(word v) { return (int)((v >> 32) & 0xF); }
+  static __device__ __forceinline__ int qa(word v) { return (int)((v >> 36) & 0xF); }
+  static __device__ __forceinline__ int da(word v) { return (int)((v >> 40) & 0xF); }
 };
 static_assert(Tier2::kCapD + 16 <= 255 && Tier2::kCapR <= 512 && Tier0::kCapR * 8 >= 6 * kInitStage * 4 && Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127, "Rec32 field widths");
 
@@ -332,7 +342,7 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
   if (flag == 0) type0 = rtype_of(type0);
   if (gl == 0) {
     S.hyb(0) = d.min_e;
-    S.info(0) = R::pack(0, 0, 0, type0, type0);
+    S.info(0) = R::pack(0, 0, 0, type0, S.qb(1), S.db(1));
     S.ptab(0, 0) = (uint8_t)type0; // cell (0,0) lies on anti-diagonal 0
   }
   group_sync<kLds>();
@@ -409,7 +419,8 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
       const int ci = i0 + b, cj = d.length - ci;
       const int ctype = __shfl(type1, gbase + b);
       // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
-      double bte = 1000000.0; // INF
+      const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
+      double bte = 1000000.0;                         // INF
       int bk = d.lo;
       for (int k0 = d.lo; k0 < dstart; k0 += G) {
         GP_COUNT(13);
@@ -420,13 +431,10 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
           if (ri < ci && rj < cj) {
             // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
             // offsets (ri, rj) and (ci, cj) from the start
+            const int rq = R::kBases ? R::qa(v) : (int)S.qb(ri + 1), rd = R::kBases ? R::da(v) : (int)S.db(rj + 1);
             double te;
-            if (flag == 0)
-              te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, S.qb(ci - 1), S.db(cj - 1),
-                                    S.qb(ri + 1), S.db(rj + 1));
-            else
-              te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, S.qb(ri + 1), S.db(rj + 1),
-                                    S.qb(ci - 1), S.db(cj - 1));
+            if (flag == 0) te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, nq, nd, rq, rd);
+            else te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, rq, rd, nq, nd);
             te += S.hyb(k);
             if (te < bte) {
               bte = te;
@@ -454,7 +462,7 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
       const int ptype = R::type(S.info(bk));
       if (gl == 0) {
         S.hyb(d.nrec) = bte;
-        S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), ptype);
+        S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), S.qb(ci + 1), S.db(cj + 1));
         S.ptab(cur, ci) = (uint8_t)ptype;
       }
       const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;

@@ -49,31 +49,77 @@ __device__ __forceinline__ int find_cand(const CandDev *c, int n, int64_t row) {
   return lo;
 }
 
-// One row = one (candidate, db SA entry); the query interval is walked inside the row.
+__global__ __launch_bounds__(kBlock) void k_sa_seq(PageDev pg, int32_t *sa_seq) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < pg.nchars) sa_seq[k] = seq_of(pg, pg.sa[k]);
+}
+
+// Query-side window sums (SeedSearch::CalcAccessibility): one per (candidate, query SA entry),
+// shared by all the database entries of the candidate.
+__global__ __launch_bounds__(kBlock) void k_seed_qacc(const CandDev *__restrict__ cands, int ncand, int64_t n, QBatchDev qb, int delta,
+                                                      double *__restrict__ qacc) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  int lo = 0, hi = ncand - 1; // candidate with qoff <= e
+  while (lo < hi) {
+    const int m = (lo + hi + 1) >> 1;
+    if (cands[m].qoff <= e) lo = m;
+    else hi = m - 1;
+  }
+  const CandDev c = cands[lo];
+  const int64_t qo = qb.off[c.query];
+  const int q_sp = qb.sa[qo + c.sp_q + (int)(e - c.qoff)];
+  qacc[e] = window_acc(qb.acc + qo, qb.cond + qo, q_sp, c.length, delta);
+}
+
+// One row = one (candidate, db SA entry); the query interval is walked inside the row.  The
+// count pass finds the row's candidate - a workgroup's 256 rows span at most 256 candidates,
+// whose first rows are put in LDS - and leaves it for the emit pass.
 template <bool kEmit>
 __global__ __launch_bounds__(kBlock) void k_seed(const CandDev *__restrict__ cands, int ncand, int64_t nrows, QBatchDev qb,
-                                                 PageDev pg, int delta, int32_t *__restrict__ row_count,
+                                                 PageDev pg, int delta, const double *__restrict__ qacc,
+                                                 int32_t *__restrict__ row_count, int32_t *__restrict__ row_cand,
                                                  const int64_t *__restrict__ row_off, HitSoA hits) {
+  __shared__ int64_t s_row0[kBlock + 1];
+  __shared__ int s_c0;
   const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (row >= nrows) return;
-  const CandDev c = cands[find_cand(cands, ncand, row)];
+  int ci;
+  if (kEmit) {
+    if (row >= nrows) return;
+    ci = row_cand[row];
+  } else {
+    if (threadIdx.x == 0) s_c0 = find_cand(cands, ncand, (int64_t)blockIdx.x * kBlock);
+    __syncthreads();
+    const int c0 = s_c0;
+    for (int t = threadIdx.x; t <= kBlock; t += kBlock) s_row0[t] = c0 + t < ncand ? cands[c0 + t].row0 : INT64_MAX;
+    __syncthreads();
+    if (row >= nrows) return;
+    int lo = 0, hi = kBlock; // last t with s_row0[t] <= row
+    while (lo < hi) {
+      const int m = (lo + hi + 1) >> 1;
+      if (s_row0[m] <= row) lo = m;
+      else hi = m - 1;
+    }
+    ci = c0 + lo;
+    row_cand[row] = ci;
+  }
+  const CandDev c = cands[ci];
   const int k = c.sp_db + (int)(row - c.row0);
   const int db_sp = pg.sa[k];
-  const int id = seq_of(pg, db_sp);
+  const int id = pg.sa_seq[k];
   const int st = pg.seq_length[id] - (db_sp - pg.start_pos[id]) - c.length;
   const int64_t base = (int64_t)pg.start_pos[id] - id;
   const double dba = window_acc(pg.acc + base, pg.cond + base, st, c.length, delta);
-  const int64_t qo = qb.off[c.query];
-  const int32_t *qsa = qb.sa + qo;
+  const int32_t *qsa = qb.sa + qb.off[c.query];
+  const double *qa_c = qacc + c.qoff - c.sp_q;
   int cnt = 0;
   int64_t w = kEmit ? row_off[row] : 0;
   for (int j = c.sp_q; j <= c.ep_q; j++) {
-    const int q_sp = qsa[j];
-    const double qa = window_acc(qb.acc + qo, qb.cond + qo, q_sp, c.length, delta);
+    const double qa = qa_c[j];
     const double ie = qa + dba + c.score;
     if (ie < 0) {
       if (kEmit) {
-        hits.q_sp[w] = q_sp;
+        hits.q_sp[w] = qsa[j];
         hits.db_sp[w] = db_sp;
         hits.q_len[w] = c.length;
         hits.db_len[w] = c.length;
@@ -537,18 +583,30 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlo
 
 } // namespace
 
+hipError_t launch_sa_seq(const PageDev &pg, int32_t *sa_seq, hipStream_t s) {
+  if (pg.nchars <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sa_seq, grid_for(pg.nchars), dim3(kBlock), 0, s, pg, sa_seq);
+  return hipGetLastError();
+}
+hipError_t launch_seed_qacc(const CandDev *cands, int32_t ncand, int64_t nq_entries, const QBatchDev &qb, int delta, double *qacc,
+                            hipStream_t s) {
+  if (nq_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_seed_qacc, grid_for(nq_entries), dim3(kBlock), 0, s, cands, ncand, nq_entries, qb, delta, qacc);
+  return hipGetLastError();
+}
 hipError_t launch_seed_count(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
-                             int delta, int32_t *row_count, hipStream_t s) {
+                             int delta, const double *qacc, int32_t *row_count, int32_t *row_cand, hipStream_t s) {
   if (nrows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_seed<false>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, qb, pg, delta, row_count,
-                     (const int64_t *)nullptr, HitSoA{});
+  hipLaunchKernelGGL(k_seed<false>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, qb, pg, delta, qacc, row_count,
+                     row_cand, (const int64_t *)nullptr, HitSoA{});
   return hipGetLastError();
 }
 hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
-                            int delta, const int64_t *row_off, HitSoA hits, hipStream_t s) {
+                            int delta, const double *qacc, const int32_t *row_cand, const int64_t *row_off, HitSoA hits,
+                            hipStream_t s) {
   if (nrows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_seed<true>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, qb, pg, delta,
-                     (int32_t *)nullptr, row_off, hits);
+  hipLaunchKernelGGL(k_seed<true>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, qb, pg, delta, qacc,
+                     (int32_t *)nullptr, const_cast<int32_t *>(row_cand), row_off, hits);
   return hipGetLastError();
 }
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc, ExtOpts o,

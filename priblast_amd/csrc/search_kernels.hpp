@@ -46,6 +46,7 @@ struct SearchConst {
 struct PageDev {
   const uint8_t *seqs; // page text: reversed sequences, 0 after each
   const int32_t *sa;
+  const int32_t *sa_seq;  // sequence that SA entry k lies in (GetSeqIdAndStart's search, done once per page)
   const int32_t *start_pos;
   const int32_t *seq_length;
   const float *acc;  // padded to L per sequence; sequence id at start_pos[id] - id
@@ -67,6 +68,7 @@ struct CandDev { // SeedCandidate + first row of the candidate (one row per db S
   int32_t sp_q, ep_q, sp_db, ep_db, length, query;
   double score;
   int64_t row0;
+  int64_t qoff; // first of the candidate's ep_q - sp_q + 1 entries in the query-side window sums
 };
 
 struct HitSoA {
@@ -84,10 +86,16 @@ struct ExtOpts {
 };
 
 // ---- seeds ----
-hipError_t launch_seed_count(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb,
-                             const PageDev &pg, int delta, int32_t *row_count, hipStream_t s);
-hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb,
-                            const PageDev &pg, int delta, const int64_t *row_off, HitSoA hits, hipStream_t s);
+// sa_seq[k] for every SA entry of a page
+hipError_t launch_sa_seq(const PageDev &pg, int32_t *sa_seq, hipStream_t s);
+// qacc[c.qoff + t] = accessibility energy of the query window of candidate c at its SA entry sp_q + t
+hipError_t launch_seed_qacc(const CandDev *cands, int32_t ncand, int64_t nq_entries, const QBatchDev &qb, int delta, double *qacc,
+                            hipStream_t s);
+hipError_t launch_seed_count(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
+                             int delta, const double *qacc, int32_t *row_count, int32_t *row_cand, hipStream_t s);
+hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
+                            int delta, const double *qacc, const int32_t *row_cand, const int64_t *row_off, HitSoA hits,
+                            hipStream_t s);
 // ---- ungapped ----
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc,
                            ExtOpts o, int max_query_len, hipStream_t s);
