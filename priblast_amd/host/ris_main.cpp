@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,7 +51,7 @@ void usage() {
             "    -a STR    accepted for compatibility (block, area, dynamic); ignored\n"
             "    -p STR    accepted for compatibility; ignored\n"
             "\n"
-            "  Environment: PRB_DEVICES=0,1,..  GPUs to use;  PRB_BATCH=N  queries per batch [default 1024]");
+            "  Environment: PRB_DEVICES=0,1,..  GPUs to use;  PRB_BATCH=N  queries per batch [default 2048]");
 }
 
 struct Args {
@@ -68,9 +70,89 @@ struct Worker {
   prb_db *db = nullptr;
 };
 
-// lines of one batch, without the Id column (SaveMyResults, rna_interaction_search.cpp:322-369)
-void run_batch(Worker &w, const Args &a, const std::vector<std::string> &names, const std::vector<std::string> &seqs,
-               size_t b0, size_t b1, int W, int delta, int repeat_flag, int npages, std::string &lines) {
+// The hit sets of one batch (one per database page), waiting to be turned into text.
+struct BatchJob {
+  size_t index = 0, b0 = 0, nq = 0;
+  Worker *w = nullptr;
+  std::vector<prb_hitset *> pages;
+  std::vector<int32_t> qlen_unmasked;
+};
+
+int format_threads() {
+  if (const char *e = std::getenv("PRB_HOST_THREADS")) return std::max(1, std::atoi(e));
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::min(32u, std::max(1u, hw));
+}
+
+// Lines of one batch (SaveMyResults, rna_interaction_search.cpp:322-369), query by query and page
+// by page as the reference groups them, numbered from `id0` on.  The hits of a page arrive
+// grouped by query in ascending order (sub-batches of ascending queries, each sorted by
+// (query, db position)), so a query's hits are one contiguous range per page; queries are
+// formatted in parallel.
+int64_t format_batch(const BatchJob &job, const Args &a, const std::vector<std::string> &names, int64_t id0, std::FILE *out) {
+  const size_t nq = job.nq, np = job.pages.size();
+  std::vector<std::vector<int64_t>> first(np, std::vector<int64_t>(nq + 1, 0)); // first[p][q] = first hit of query q
+  for (size_t p = 0; p < np; p++) {
+    const int64_t n = prb_hitset_size(job.pages[p]);
+    const prb_hit *h = prb_hitset_hits(job.pages[p]);
+    size_t q = 0;
+    for (int64_t i = 0; i < n; i++)
+      while (q < nq && (int64_t)q <= h[i].query) first[p][q++] = i;
+    while (q <= nq) first[p][q++] = n;
+  }
+  std::vector<int64_t> base(nq + 1, id0);
+  for (size_t q = 0; q < nq; q++) {
+    int64_t c = 0;
+    for (size_t p = 0; p < np; p++) c += first[p][q + 1] - first[p][q];
+    base[q + 1] = base[q] + c;
+  }
+  std::vector<std::string> text(nq);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(format_threads())
+  for (size_t q = 0; q < nq; q++) {
+    std::string &s = text[q];
+    s.reserve((size_t)(base[q + 1] - base[q]) * 80);
+    char buf[512];
+    int64_t id = base[q];
+    for (size_t p = 0; p < np; p++) {
+      const prb_hit *h = prb_hitset_hits(job.pages[p]);
+      int64_t nbp = 0;
+      const int32_t *bp = prb_hitset_basepairs(job.pages[p], &nbp);
+      for (int64_t i = first[p][q]; i < first[p][q + 1]; i++) {
+        const prb_hit &x = h[i];
+        int32_t len = 0, len_rep = 0, sp = 0;
+        prb_db_seq_lengths(job.w->db, (int32_t)p, x.db_id, &len, &len_rep, &sp);
+        std::snprintf(buf, sizeof buf, "%lld,", (long long)id++);
+        s += buf;
+        s += names[job.b0 + q];
+        std::snprintf(buf, sizeof buf, ",%d,", job.qlen_unmasked[q]);
+        s += buf;
+        s += prb_db_seq_name(job.w->db, (int32_t)p, x.db_id);
+        std::snprintf(buf, sizeof buf, ",%d,%g,%g,%g,", len_rep, x.e_acc, x.e_hyb, x.e_tot);
+        s += buf;
+        const int32_t *pp = bp + 2 * x.bp_offset;
+        auto fwd = [&](int32_t dbpos) { return (len - 1) - (dbpos - sp); }; // reversed text -> forward coordinate
+        if (a.o.output_style == 1) {
+          for (int32_t j = 0; j < x.bp_count; j++) {
+            std::snprintf(buf, sizeof buf, "(%d:%d) ", pp[2 * j], fwd(pp[2 * j + 1]));
+            s += buf;
+          }
+        } else if (x.bp_count > 0) {
+          const int32_t l = x.bp_count - 1;
+          std::snprintf(buf, sizeof buf, "(%d-%d:%d-%d) ", pp[0], pp[2 * l], fwd(pp[1]), fwd(pp[2 * l + 1]));
+          s += buf;
+        }
+        s += "\n";
+      }
+    }
+  }
+  for (auto &s : text)
+    if (!s.empty() && std::fwrite(s.data(), 1, s.size(), out) != s.size()) die("Error: can't write the output file");
+  return base[nq];
+}
+
+// One batch through the GPU stages; the hit sets go to the writer.
+void run_batch(Worker &w, const Args &a, const std::vector<std::string> &seqs, size_t b0, size_t b1, int W, int delta,
+               int repeat_flag, int npages, BatchJob &job) {
   std::string cat;
   std::vector<int64_t> off(b1 - b0 + 1, 0);
   for (size_t i = b0; i < b1; i++) {
@@ -80,45 +162,17 @@ void run_batch(Worker &w, const Args &a, const std::vector<std::string> &names, 
   prb_qbatch *qb = nullptr;
   if (prb_qbatch_create(w.ctx, (int32_t)(b1 - b0), cat.data(), off.data(), repeat_flag, &qb)) die(prb_last_error());
   if (prb_qbatch_accessibility(w.ctx, qb, W, delta)) die(prb_last_error());
-  // per query, pages in order: collect per (query, page) so the text is grouped like the reference's
-  std::vector<std::string> per_q(b1 - b0);
-  char buf[512];
+  job.b0 = b0;
+  job.nq = b1 - b0;
+  job.w = &w;
+  job.qlen_unmasked.resize(job.nq);
+  for (size_t q = 0; q < job.nq; q++) job.qlen_unmasked[q] = prb_qbatch_length_unmasked(qb, (int32_t)q);
   for (int page = 0; page < npages; page++) {
     prb_hitset *hs = nullptr;
     if (prb_search_page(w.ctx, qb, w.db, page, &a.o, 3, &hs)) die(prb_last_error());
-    const int64_t n = prb_hitset_size(hs);
-    const prb_hit *h = prb_hitset_hits(hs);
-    int64_t nbp = 0;
-    const int32_t *bp = prb_hitset_basepairs(hs, &nbp);
-    for (int64_t i = 0; i < n; i++) {
-      const prb_hit &x = h[i];
-      int32_t len = 0, len_rep = 0, sp = 0;
-      prb_db_seq_lengths(w.db, page, x.db_id, &len, &len_rep, &sp);
-      std::string &s = per_q[x.query];
-      std::snprintf(buf, sizeof buf, ",%d,", prb_qbatch_length_unmasked(qb, x.query));
-      s += names[b0 + x.query];
-      s += buf;
-      s += prb_db_seq_name(w.db, page, x.db_id);
-      std::snprintf(buf, sizeof buf, ",%d,%g,%g,%g,", len_rep, x.e_acc, x.e_hyb, x.e_tot);
-      s += buf;
-      const int32_t *p = bp + 2 * x.bp_offset;
-      auto fwd = [&](int32_t dbpos) { return (len - 1) - (dbpos - sp); }; // reversed text -> forward coordinate
-      if (a.o.output_style == 1) {
-        for (int32_t j = 0; j < x.bp_count; j++) {
-          std::snprintf(buf, sizeof buf, "(%d:%d) ", p[2 * j], fwd(p[2 * j + 1]));
-          s += buf;
-        }
-      } else if (x.bp_count > 0) {
-        const int32_t l = x.bp_count - 1;
-        std::snprintf(buf, sizeof buf, "(%d-%d:%d-%d) ", p[0], p[2 * l], fwd(p[1]), fwd(p[2 * l + 1]));
-        s += buf;
-      }
-      s += "\n";
-    }
-    prb_hitset_free(hs);
+    job.pages.push_back(hs);
   }
   prb_qbatch_destroy(qb);
-  for (auto &s : per_q) lines += s;
 }
 
 int ris_main(int argc, char **argv) {
@@ -182,31 +236,57 @@ int ris_main(int argc, char **argv) {
                     "Interaction Energy, BasePair\n");
 
   const char *benv = std::getenv("PRB_BATCH");
-  const size_t batch = std::max(1, benv ? std::atoi(benv) : 1024);
+  const size_t batch = std::max(1, benv ? std::atoi(benv) : 2048);
   const size_t nb = (seqs.size() + batch - 1) / batch;
-  std::vector<std::string> results(nb);
+  // GPU workers take batches from a counter; a writer thread turns finished batches into text in
+  // batch order while the GPUs already work on the next ones (at most two finished batches per
+  // worker wait for it).
   std::atomic<size_t> next{0};
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<size_t, BatchJob> done;
+  size_t written = 0;
+  std::thread writer([&] {
+    int64_t id = 0;
+    for (size_t b = 0; b < nb; b++) {
+      BatchJob job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done.count(b) != 0; });
+        job = std::move(done[b]);
+        done.erase(b);
+      }
+      id = format_batch(job, a, names, id, out);
+      for (prb_hitset *hs : job.pages) prb_hitset_free(hs);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        written = b + 1;
+      }
+      cv.notify_all();
+    }
+  });
   std::vector<std::thread> threads;
   for (auto &w : workers)
     threads.emplace_back([&, pw = &w] {
       for (;;) {
         const size_t b = next.fetch_add(1);
         if (b >= nb) break;
-        run_batch(*pw, a, names, seqs, b * batch, std::min(seqs.size(), (b + 1) * batch), W, delta, repeat_flag, npages,
-                  results[b]);
+        {
+          std::unique_lock<std::mutex> lk(mu); // bound the hit sets held in memory
+          cv.wait(lk, [&] { return b < written + 2 * workers.size() + 1; });
+        }
+        BatchJob job;
+        job.index = b;
+        run_batch(*pw, a, seqs, b * batch, std::min(seqs.size(), (b + 1) * batch), W, delta, repeat_flag, npages, job);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          done[b] = std::move(job);
+        }
+        cv.notify_all();
       }
     });
   for (auto &t : threads) t.join();
-  long id = 0;
-  for (auto &r : results) {
-    const char *p = r.data(), *end = p + r.size();
-    while (p < end) {
-      const char *nl = static_cast<const char *>(std::memchr(p, '\n', end - p));
-      std::fprintf(out, "%ld,", id++);
-      std::fwrite(p, 1, nl - p + 1, out);
-      p = nl + 1;
-    }
-  }
+  writer.join();
   std::fclose(out);
   for (auto &w : workers) {
     prb_db_close(w.db);
