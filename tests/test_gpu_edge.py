@@ -1,0 +1,130 @@
+"""GPU edge cases and size-independent properties through the C ABI.
+
+* degenerate queries (shorter than the accessibility window, shorter than a seed, unknown bases,
+  soft-masked, homopolymers) against the oracle, query by query;
+* an empty batch and a batch without any hit;
+* properties that need no oracle and therefore run at a larger size: the results of a query do
+  not depend on what else is in its batch, on the batch order, or on how the search is cut into
+  sub-batches; hit sets come back grouped by query."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import refdump
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+DEGENERATE = [
+    "A", "ACG", "ACGU", "GGGGGCCCCC", "ACGUACGUACGU", "N" * 40, "acguacguacguggggccccaaaauuuu" * 3,
+    "A" * 60, "GC" * 40, "ACGUNNNNACGUGGGGGGGGCCCCCCCCNNACGUACGUAGCUAGCUAGCAUCGAUCGAUCG" * 3,
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from priblast_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def per_query(hits, bp, q):
+    mine = hits[hits["query"] == q]
+    out = []
+    for h in mine:
+        out.append((int(h["db_sp"]), int(h["q_sp"]), int(h["db_len"]), int(h["q_len"]), int(h["db_id"]), int(h["db_id_start"]),
+                    float(h["e_acc"]), float(h["e_hyb"]), float(h["e_tot"]),
+                    tuple(map(tuple, bp[h["bp_offset"]:h["bp_offset"] + h["bp_count"]].tolist()))))
+    return out
+
+
+def test_degenerate_queries_match_oracle(ctx, oracle, golden_dir):
+    from priblast_amd import capi
+    db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+    odb = oracle.Db(os.path.join(golden_dir, "mixdb"))
+    _, normal = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    seqs = DEGENERATE + normal[:2]
+    qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        for q, s in enumerate(seqs):
+            _, _, acc, cond = qb.get(q)
+            oacc, ocond = oracle.raccess(s, db.W, db.delta)
+            assert np.array_equal(acc[:len(s)].view(np.uint32), oacc.view(np.uint32)), (q, s[:20])
+            assert np.array_equal(cond[:len(s)].view(np.uint32), ocond.view(np.uint32)), (q, s[:20])
+        total = 0
+        for page in range(db.npages):
+            hits, bp, counts = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
+            for q, s in enumerate(seqs):
+                _, _, gap = odb.stages(s, page)
+                mine = per_query(hits, bp, q)
+                ref = [(h["db_sp"], h["q_sp"], h["db_len"], h["q_len"], h["db_id"], h["db_id_start"], h["e_acc"], h["e_hyb"],
+                        h["e_tot"], tuple(map(tuple, h["bp"].tolist()))) for h in gap]
+                assert sorted(mine) == sorted(ref), (page, q, s[:20])
+                total += len(mine)
+        assert total > 0
+    finally:
+        qb.close()
+        db.close()
+        odb.close()
+
+
+def test_empty_batch_and_hitless_batch(ctx, golden_dir):
+    from priblast_amd import capi
+    db = capi.Db(ctx, os.path.join(golden_dir, "c1db"))
+    try:
+        try:
+            qb = capi.QBatch(ctx, [], db.repeat_flag)
+        except capi.PrbError:
+            qb = None  # refusing an empty batch is fine; crashing is not
+        if qb is not None:
+            qb.accessibility(db.W, db.delta)
+            hits, bp, counts = capi.search_page(ctx, qb, db, 0)
+            assert len(hits) == 0 and counts == (0, 0, 0)
+            qb.close()
+        qb = capi.QBatch(ctx, ["A" * 50, "N" * 30, "ACA"], db.repeat_flag)  # nothing can pair with a poly-A / unknown bases
+        qb.accessibility(db.W, db.delta)
+        hits, bp, counts = capi.search_page(ctx, qb, db, 0)
+        assert len(hits) == 0 and counts[2] == 0
+        qb.close()
+    finally:
+        db.close()
+
+
+def test_results_do_not_depend_on_batch_composition(ctx, golden_dir, monkeypatch):
+    """64 random 300-nt queries vs the paged database: the same per-query results whether a
+    query runs alone, in the full batch, in the reversed batch, or with tiny sub-batches."""
+    from priblast_amd import capi
+    rng = random.Random(7)
+    seqs = ["".join(rng.choice("ACGU") for _ in range(300)) for _ in range(64)]
+    db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+
+    def run(batch):
+        qb = capi.QBatch(ctx, batch, db.repeat_flag)
+        qb.accessibility(db.W, db.delta)
+        res = [[] for _ in batch]
+        try:
+            for page in range(db.npages):
+                hits, bp, counts = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
+                assert np.all(np.diff(hits["query"]) >= 0)  # grouped by query, ascending
+                for q in range(len(batch)):
+                    res[q].append(per_query(hits, bp, q))
+        finally:
+            qb.close()
+        return res
+
+    try:
+        full = run(seqs)
+        assert sum(len(p) for r in full for p in r) > 100
+        rev = run(seqs[::-1])
+        assert rev[::-1] == full
+        monkeypatch.setenv("PRB_SEARCH_PAIRS", "20000")
+        assert run(seqs) == full
+        monkeypatch.delenv("PRB_SEARCH_PAIRS")
+        for q in (0, 17, 63):
+            assert run([seqs[q]])[0] == full[q]
+    finally:
+        db.close()
