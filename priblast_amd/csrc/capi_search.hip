@@ -605,9 +605,54 @@ namespace prb {
 // Sorts `in` (n hits) into `out` by the reference's comparator made total:
 // (query, db_sp asc, q_sp asc, db_len desc, q_len desc, energy asc, input order);
 // LSD: one stable radix sort per key, least significant first.  perm_out[i] = index in `in`.
-static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &in, HitSoA out, int64_t n, int nq, uint32_t **perm_out) {
+// Field bounds of the hits of one sub-batch, for the one-key sort
+struct SortBounds {
+  int32_t qmin = 0, qspan = 1, max_qlen = 0, max_dblen = 0, nchars = 0;
+};
+static int bits_for(int64_t max_value) {
+  int b = 1;
+  while (b < 40 && (int64_t(1) << b) <= max_value) b++;
+  return b;
+}
+
+static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &in, HitSoA out, int64_t n, int nq, const SortBounds &sb,
+                     uint32_t **perm_out) {
   int rc;
   const size_t N = (size_t)n;
+  {
+    // one stable radix sort over a packed key + a pass over the runs of identical coordinates
+    PackedKeyInfo f;
+    f.qmin = sb.qmin;
+    f.lmax = std::max(sb.max_qlen, sb.max_dblen);
+    f.bl = bits_for(f.lmax);
+    f.bq = bits_for(sb.max_qlen);
+    f.bd = bits_for(sb.nchars);
+    const int total = 2 * f.bl + f.bq + f.bd + bits_for(sb.qspan - 1);
+    if (total <= 64 && f.lmax <= 65535 && !getenv("PRB_SORT_FOUR_KEYS")) {
+      if ((rc = w.kP.ensure(N * 8)) || (rc = w.kTmp2.ensure(N * 8)) || (rc = w.kE.ensure(N * 8)) || (rc = w.kTmp.ensure(N * 8)) ||
+          (rc = w.idxA.ensure(N * 4)) || (rc = w.idxB.ensure(N * 4)) || (rc = w.pending.ensure(16)))
+        return rc;
+      PRB_HIP(launch_make_packed_keys(in, n, f, w.kP.as<uint64_t>(), w.kE.as<uint64_t>(), w.idxA.as<uint32_t>(), ctx->stream));
+      size_t tmp = 0;
+      PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.idxA.as<uint32_t>(),
+                                        w.idxB.as<uint32_t>(), N, 0, (unsigned)total, ctx->stream));
+      if ((rc = w.sortTmp.ensure(tmp))) return rc;
+      PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.idxA.as<uint32_t>(),
+                                        w.idxB.as<uint32_t>(), N, 0, (unsigned)total, ctx->stream));
+      PRB_HIP(launch_gather_u64(w.kE.as<uint64_t>(), w.idxB.as<uint32_t>(), w.kTmp.as<uint64_t>(), n, ctx->stream));
+      PRB_HIP(hipMemsetAsync(w.pending.p, 0, 4, ctx->stream));
+      PRB_HIP(launch_fix_ties(w.kTmp2.as<uint64_t>(), w.kTmp.as<uint64_t>(), w.idxB.as<uint32_t>(), n, w.pending.as<int32_t>(),
+                              ctx->stream));
+      int32_t too_long = 0;
+      PRB_HIP(hipMemcpyAsync(&too_long, w.pending.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      if (!too_long) {
+        PRB_HIP(launch_gather_hits(in, w.idxB.as<uint32_t>(), out, n, ctx->stream));
+        *perm_out = w.idxB.as<uint32_t>();
+        return PRB_OK;
+      }
+    }
+  }
   if ((rc = w.kE.ensure(N * 8)) || (rc = w.kL.ensure(N * 4)) || (rc = w.kQ.ensure(N * 4)) || (rc = w.kP.ensure(N * 8)) ||
       (rc = w.kTmp.ensure(N * 8)) || (rc = w.kTmp2.ensure(N * 8)) || (rc = w.idxA.ensure(N * 4)) ||
       (rc = w.idxB.ensure(N * 4)))
@@ -793,6 +838,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = ctx->time_begin())) return rc;
   int max_qlen = 0;
   for (int32_t q = 0; q < qb->nq; q++) max_qlen = std::max(max_qlen, qb->len[q]);
+  SortBounds sb;
+  sb.qmin = cd[0].query; // the candidates are in query order
+  sb.qspan = cd[ncand - 1].query - cd[0].query + 1;
+  sb.max_qlen = max_qlen;
+  for (int32_t L : pg.seq_length) sb.max_dblen = std::max(sb.max_dblen, L);
+  sb.nchars = pd.nchars;
   PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, max_qlen, ctx->stream));
   if ((rc = ctx->time_end("ungapped", 1))) return rc;
   // hits above the -f threshold are dropped before the sort (they cannot survive the filter)
@@ -807,7 +858,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   HitSoA B = carve_hits(w.hitsC, m1);
   uint32_t *perm = nullptr;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, A2, B, m1, qb->nq, &perm))) return rc;
+  if ((rc = sort_hits(ctx, w, A2, B, m1, qb->nq, sb, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nung = 0;
   if ((rc = ctx->time_begin())) return rc;
@@ -956,7 +1007,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if (m2 == 0) return PRB_OK;
   HitSoA S = carve_hits(w.hitsC, m2); // G is dead after the compaction
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, G2, S, m2, qb->nq, &perm))) return rc;
+  if ((rc = sort_hits(ctx, w, G2, S, m2, qb->nq, sb, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nfin = 0;
   if ((rc = ctx->time_begin())) return rc;

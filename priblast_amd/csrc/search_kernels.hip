@@ -422,6 +422,53 @@ __global__ __launch_bounds__(kBlock) void k_make_keys(HitSoA h, int64_t n, uint6
   idx[i] = (uint32_t)i;
 }
 
+// The same order from ONE 64-bit key when the fields are narrow enough (they are for every page
+// of up to 2^27 characters and sequences of up to a few thousand nucleotides): query (relative to
+// the sub-batch) | db_sp | q_sp | lmax - db_len | lmax - q_len.  A single stable radix sort over
+// the used bits then leaves only the hits with identical coordinates to be put in (energy, input
+// order) order, which k_fix_ties does run by run.
+__global__ __launch_bounds__(kBlock) void k_make_packed_keys(HitSoA h, int64_t n, PackedKeyInfo f, uint64_t *key,
+                                                             uint64_t *k_energy, uint32_t *idx) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t eb = (uint64_t)__double_as_longlong(h.e_tot[i]);
+  k_energy[i] = (eb >> 63) ? ~eb : (eb | 0x8000000000000000ull);
+  uint64_t k = (uint64_t)(uint32_t)(h.query[i] - f.qmin);
+  k = (k << f.bd) | (uint32_t)h.db_sp[i];
+  k = (k << f.bq) | (uint32_t)h.q_sp[i];
+  k = (k << f.bl) | (uint32_t)(f.lmax - US(h.db_len[i]));
+  k = (k << f.bl) | (uint32_t)(f.lmax - US(h.q_len[i]));
+  key[i] = k;
+  idx[i] = (uint32_t)i;
+}
+
+constexpr int kMaxTieRun = 4096;
+__global__ __launch_bounds__(kBlock) void k_fix_ties(const uint64_t *__restrict__ key, uint64_t *e, uint32_t *perm, int64_t n,
+                                                     int32_t *too_long) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || i + 1 >= n) return;
+  const uint64_t k = key[i];
+  if ((i > 0 && key[i - 1] == k) || key[i + 1] != k) return; // not the first element of a run of equal keys
+  int64_t end = i + 2;
+  while (end < n && key[end] == k && end - i <= kMaxTieRun) end++;
+  if (end - i > kMaxTieRun) {
+    *too_long = 1;
+    return;
+  }
+  for (int64_t a = i + 1; a < end; a++) { // insertion sort by (energy, input index); the input is in index order
+    const uint64_t ea = e[a];
+    const uint32_t pa = perm[a];
+    int64_t b = a - 1;
+    while (b >= i && (e[b] > ea || (e[b] == ea && perm[b] > pa))) {
+      e[b + 1] = e[b];
+      perm[b + 1] = perm[b];
+      b--;
+    }
+    e[b + 1] = ea;
+    perm[b + 1] = pa;
+  }
+}
+
 template <class T> __global__ __launch_bounds__(kBlock) void k_gather(const T *src, const uint32_t *idx, T *dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
@@ -624,6 +671,18 @@ hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, u
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_make_keys, grid_for(n), dim3(kBlock), 0, s, hits, n, k_energy, k_len, k_qsp, k_pos, idx);
+  return hipGetLastError();
+}
+hipError_t launch_make_packed_keys(const HitSoA &hits, int64_t n, const PackedKeyInfo &f, uint64_t *key, uint64_t *k_energy,
+                                   uint32_t *idx, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_make_packed_keys, grid_for(n), dim3(kBlock), 0, s, hits, n, f, key, k_energy, idx);
+  return hipGetLastError();
+}
+hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, int32_t *too_long,
+                           hipStream_t s) {
+  if (n <= 1) return hipSuccess;
+  hipLaunchKernelGGL(k_fix_ties, grid_for(n), dim3(kBlock), 0, s, key_sorted, e_sorted, perm, n, too_long);
   return hipGetLastError();
 }
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s) {

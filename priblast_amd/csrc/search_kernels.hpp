@@ -100,6 +100,17 @@ hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, 
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc,
                            ExtOpts o, int max_query_len, hipStream_t s);
 // ---- sort keys / gather ----
+// One-key form of the sort (when the fields fit 64 bits): field widths and the offsets
+struct PackedKeyInfo {
+  int32_t qmin, lmax; // first query of the sub-batch; upper bound of q_len / db_len
+  int32_t bl, bq, bd; // bits of a length, of q_sp, of db_sp
+};
+hipError_t launch_make_packed_keys(const HitSoA &hits, int64_t n, const PackedKeyInfo &f, uint64_t *key, uint64_t *k_energy,
+                                   uint32_t *idx, hipStream_t s);
+// after the stable sort by the packed key: runs of equal keys -> (energy, input index) order; *too_long is
+// set if a run is longer than the kernel handles (the caller then sorts by the four keys instead)
+hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, int32_t *too_long,
+                           hipStream_t s);
 hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, uint32_t *k_len, uint32_t *k_qsp,
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s);
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
