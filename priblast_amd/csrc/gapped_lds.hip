@@ -391,19 +391,19 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
     const int i = i0 + gl, j = d.length - i;
     int type1 = 0;
     if (i <= i_hi) {
-      // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases
-      type1 = bp_type(sc, S.qb(i), S.db(j));
+      // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases.  Everything it can
+      // need for a minimum helix of up to 3 is fetched at once (one LDS round trip instead of four).
+      const int q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
+      const int pt = S.ptab(d2, i - 1);
+      type1 = bp_type(sc, q0, d0);
       if (flag == 1) type1 = rtype_of(type1);
-      if (type1 != 0) {
-        const int pt = S.ptab(d2, i - 1);
-        if (pt == 0 || (wobble(type1) && wobble(pt))) {
-          for (int x = 1; x <= min_helix - 1; x++) {
-            int t = bp_type(sc, S.qb(i + x), S.db(j + x));
-            if (flag == 1) t = rtype_of(t);
-            if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
-              type1 = 0;
-              break;
-            }
+      if (type1 != 0 && (pt == 0 || (wobble(type1) && wobble(pt)))) {
+        for (int x = 1; x <= min_helix - 1; x++) {
+          int t = x == 1 ? bp_type(sc, q1, d1) : x == 2 ? bp_type(sc, q2, d2b) : bp_type(sc, S.qb(i + x), S.db(j + x));
+          if (flag == 1) t = rtype_of(t);
+          if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
+            type1 = 0;
+            break;
           }
         }
       }
@@ -420,6 +420,7 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
       const int ctype = __shfl(type1, gbase + b);
       // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
       const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
+      const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1); // needed after the scan; fetched behind it
       double bte = 1000000.0;                         // INF
       int bk = d.lo;
       for (int k0 = d.lo; k0 < dstart; k0 += G) {
@@ -427,6 +428,7 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
         const int k = k0 + gl;
         if (k < dstart) {
           const auto v = S.info(k);
+          const double hk = S.hyb(k); // issued with the record: its latency overlaps the energy look-ups
           const int ri = R::i(v), rj = R::j(v);
           if (ri < ci && rj < cj) {
             // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
@@ -435,7 +437,7 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
             double te;
             if (flag == 0) te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, nq, nd, rq, rd);
             else te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, rq, rd, nq, nd);
-            te += S.hyb(k);
+            te += hk;
             if (te < bte) {
               bte = te;
               bk = k;
@@ -465,10 +467,10 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
         S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), S.qb(ci + 1), S.db(cj + 1));
         S.ptab(cur, ci) = (uint8_t)ptype;
       }
-      const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;
+      const double ie = eq_c + ed_c + bte;
       if (ie < d.min_e) {
         d.min_e = ie;
-        d.min_a = d.first_a + S.eq(ci - 1) + S.ed(cj - 1);
+        d.min_a = d.first_a + eq_c + ed_c;
         d.min_length = d.length;
         d.best = d.nrec;
         if (flag == 0) {
