@@ -175,6 +175,39 @@ template <bool kLds> __device__ __forceinline__ void group_sync() {
   }
 }
 
+// (energy, key) minimum over a group of G lanes, every lane ends with the result.  Groups of 8 and
+// 16 lanes stay on the VALU (DPP: quad permutes, then half-row / row mirror) - the step is on the
+// critical path of every filled cell and an LDS-routed shuffle costs ~100 cycles of latency each.
+template <int kCtrl> __device__ __forceinline__ void min_step_dpp(double &te, int &key) {
+  const int lo = __double2loint(te), hi = __double2hiint(te);
+  const int olo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, 0xF, 0xF, false);
+  const int ohi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, 0xF, 0xF, false);
+  const int ok = __builtin_amdgcn_update_dpp(0, key, kCtrl, 0xF, 0xF, false);
+  const double ote = __hiloint2double(ohi, olo);
+  if (ote < te || (ote == te && ok < key)) {
+    te = ote;
+    key = ok;
+  }
+}
+template <int G> __device__ __forceinline__ void group_min(double &te, int &key) {
+  if (G == 8 || G == 16) {
+    min_step_dpp<0xB1>(te, key);  // quad_perm [1,0,3,2]
+    min_step_dpp<0x4E>(te, key);  // quad_perm [2,3,0,1]
+    min_step_dpp<0x141>(te, key); // row_half_mirror: lane i <-> 7 - i
+    if (G == 16) min_step_dpp<0x140>(te, key); // row_mirror: lane i <-> 15 - i
+  } else {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+      const double ote = __shfl_xor(te, m);
+      const int ok = __shfl_xor(key, m);
+      if (ote < te || (ote == te && ok < key)) {
+        te = ote;
+        key = ok;
+      }
+    }
+  }
+}
+
 struct DirResult {
   bool overflow;
   int best; // cell index of the arg-min, 0 = nothing found
@@ -421,8 +454,9 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
       // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
       const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
       const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1); // needed after the scan; fetched behind it
-      double bte = 1000000.0;                         // INF
-      int bk = d.lo;
+      const int fq = S.qb(ci + 1), fd = S.db(cj + 1);        // likewise: the new record's far-side bases
+      double bte = 1000000.0;                                // INF
+      int bkp = d.lo << 3; // candidate index << 3 | its type (0: none looked at), so the type comes out of the reduction
       for (int k0 = d.lo; k0 < dstart; k0 += G) {
         GP_COUNT(13);
         const int k = k0 + gl;
@@ -440,31 +474,24 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
             te += hk;
             if (te < bte) {
               bte = te;
-              bk = k;
+              bkp = (k << 3) | R::type(v);
             }
           }
         }
       }
       GP_MARK(4);
-#pragma unroll
-      for (int m = G / 2; m >= 1; m >>= 1) { // (energy, index) minimum over the group
-        const double ote = __shfl_xor(bte, m);
-        const int ok = __shfl_xor(bk, m);
-        if (ote < bte || (ote == bte && ok < bk)) {
-          bte = ote;
-          bk = ok;
-        }
-      }
+      group_min<G>(bte, bkp); // "first candidate in list order wins under strict <"
       GP_MARK(5);
       if (d.nrec >= S.cap_r()) {
         d.overflow = true;
         break;
       }
-      if (d.lo >= dstart) bk = 0; // empty window: the reference reads stem_candidate[0] of an empty list
-      const int ptype = R::type(S.info(bk));
+      int bk = bkp >> 3, ptype = bkp & 7;
+      if (d.lo >= dstart) bk = 0;                  // empty window: the reference reads stem_candidate[0] of an empty list
+      if (ptype == 0) ptype = R::type(S.info(bk)); // no candidate qualified: the type of that default entry
       if (gl == 0) {
         S.hyb(d.nrec) = bte;
-        S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), S.qb(ci + 1), S.db(cj + 1));
+        S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
         S.ptab(cur, ci) = (uint8_t)ptype;
       }
       const double ie = eq_c + ed_c + bte;
