@@ -441,7 +441,10 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
         }
       }
     }
-    unsigned long long vmask = __ballot(type1 != 0);
+    // the types of the chunk's cells as three bit planes: a lane reads any cell's type from them
+    // without going through LDS
+    const unsigned long long tb0 = __ballot(type1 & 1), tb1 = __ballot(type1 & 2), tb2 = __ballot(type1 & 4);
+    unsigned long long vmask = tb0 | tb1 | tb2;
     if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
     GP_MARK(3);
     GP_COUNT(11);
@@ -450,19 +453,31 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
       const int b = __builtin_ctzll(vmask);
       vmask &= vmask - 1;
       const int ci = i0 + b, cj = d.length - ci;
-      const int ctype = __shfl(type1, gbase + b);
+      const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
+                        (int)(((tb2 >> (gbase + b)) & 1) << 2);
       // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
       const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
       const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1); // needed after the scan; fetched behind it
       const int fq = S.qb(ci + 1), fd = S.db(cj + 1);        // likewise: the new record's far-side bases
       double bte = 1000000.0;                                // INF
       int bkp = d.lo << 3; // candidate index << 3 | its type (0: none looked at), so the type comes out of the reduction
+      // (the records of the next round are fetched while this round's energies are looked up)
+      typename R::word vn = 0;
+      double hn = 0;
+      if (d.lo + gl < dstart) {
+        vn = S.info(d.lo + gl);
+        hn = S.hyb(d.lo + gl);
+      }
       for (int k0 = d.lo; k0 < dstart; k0 += G) {
         GP_COUNT(13);
         const int k = k0 + gl;
+        const auto v = vn;
+        const double hk = hn;
+        if (k + G < dstart) {
+          vn = S.info(k + G);
+          hn = S.hyb(k + G);
+        }
         if (k < dstart) {
-          const auto v = S.info(k);
-          const double hk = S.hyb(k); // issued with the record: its latency overlaps the energy look-ups
           const int ri = R::i(v), rj = R::j(v);
           if (ri < ci && rj < cj) {
             // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
