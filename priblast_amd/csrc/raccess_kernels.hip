@@ -575,6 +575,92 @@ __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v,
   }
 }
 
+// Linear branch, float-overflow regime: the un-normalised sums are only ever used as
+// `(float)sum` under a log, and fmath::log(+inf) is the constant 88.722839.  A position whose sum
+// contains ONE term expd(e) with e >= 89 (> FLT_MAX by a third) therefore has the same final value
+// whatever the other terms and their order are, and a position without any non-zero term
+// (e <= -708.39.. for all of them) stays exactly 0.  This pass only classifies: per position and
+// per sum (bulge/interior "b", conditional "c") two bits - some term is that large / some term is
+// non-zero - as order-independent ORs over the same (i, j, p, q) enumeration, without the
+// tuple-by-tuple scatter.  It stores +inf / 0 where that decides the result (k_access's
+// finalisation then takes the same branches as with the true sums) and returns false when some
+// position needs its true sum, in which case the caller runs the ordered pass.  For random RNA
+// of 1 kb (log Z ~ 270) every position is decided here.
+__device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqView &v, int delta, int lane) {
+  const int L = v.L, W = v.W, S = v.S;
+  const unsigned char *s = v.s;
+  const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
+  double *bp = v.v(V_BP), *cbp = v.v(V_CBP);
+  // flags of position k live on lane k & 63, slot (k >> 6) & 1: bit 0 b-big, 1 b-nonzero, 2 c-big, 3 c-nonzero
+  unsigned f0 = 0, f1 = 0;
+  bool undecided = false;
+  auto flush = [&](int k) {
+    if ((k & 63) == lane) {
+      const bool sl = (k >> 6) & 1;
+      const unsigned f = sl ? f1 : f0;
+      const bool bbig = f & 1, bnz = f & 2, cbig = f & 4, cnz = f & 8;
+      if (!((cbig || !cnz) && (cbig || bbig || !bnz))) undecided = true;
+      bp[k - 1] = bnz ? __builtin_huge_val() : 0.0;
+      cbp[k - 1] = cnz ? __builtin_huge_val() : 0.0;
+      if (sl) f1 = 0;
+      else f0 = 0;
+    }
+  };
+  for (int i = 1; i < L - kTurn - 2; i++) {
+    const int kb = i + 1; // smallest position this and later i can touch
+    const int jend = imin(i + W, L);
+    for (int j = i + kTurn + 3; j <= jend; j++) {
+      const int type = ra_bp(lds, s[i], s[j]);
+      if (type == 0) continue;
+      const double bs = EM(b_stemend, i, j - 1);
+      if (bs == kNegInf) continue;
+      const int D = j - i;
+      const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
+      const int bi1 = s[i + 1], bj1 = s[j - 1];
+      const int kr1 = j - delta;
+      for (int u1 = 0; u1 <= m; u1++) {
+        const int p = i + 1 + u1;
+        const int u2 = (m - u1) - lane; // lane t holds q = q0 + t, q0 = j - 1 - (m - u1)
+        bool big = false, nz = false;
+        if (u2 >= 0 && !(u1 == 0 && u2 == 0)) {
+          const int q = j - 1 - u2;
+          int type2 = ra_bp(lds, s[p], s[q]);
+          const double as = EM(a_stem, p - 1, q);
+          if (type2 != 0 && as != kNegInf) {
+            type2 = ra_rtype(type2);
+            const double e = bs + ra_loop_energy(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
+            nz = e > -708.39641853226408; // ra_expd(e) != 0
+            big = e >= 89.0;
+          }
+        }
+        const unsigned long long nzmask = __ballot(nz);
+        if (nzmask == 0) continue;
+        const unsigned long long bigmask = __ballot(big);
+        const int kl1 = p - delta; // left range [i+1, p-delta], shared by all q of this p
+        const int q0 = j - 1 - (m - u1);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int k = kb + ((lane - kb) & 63) + 64 * h;
+          unsigned add = 0;
+          if (k <= kl1) add |= (k == kl1 ? 2u : 8u) | (bigmask ? (k == kl1 ? 1u : 4u) : 0u);
+          if (k <= kr1) { // right ranges [q+1, j-delta]: the tuples with q <= k - 1, i.e. lanes t < k - q0
+            const int nl = k - q0;
+            if (nl > 0) {
+              const unsigned long long below = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+              if (nzmask & below) add |= (k == kr1 ? 2u : 8u) | ((bigmask & below) ? (k == kr1 ? 1u : 4u) : 0u);
+            }
+          }
+          if ((k >> 6) & 1) f1 |= add;
+          else f0 |= add;
+        }
+      }
+    }
+    flush(kb); // position i+1 receives nothing from later i
+  }
+  for (int k = imax(2, L - kTurn - 2 + 1); k <= L; k++) flush(k);
+  return __ballot(undecided) == 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
   ra_load_lds(lds, c);
@@ -583,8 +669,12 @@ __global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
   if (idx >= b.nseq) return;
   const SeqView v = make_view(b, idx);
   const double pf = v.v(V_AO)[v.L];
-  if (pf >= -690 && pf <= 690) biloop_run<false>(lds, c, v, b.delta, lane); // raccess.cpp:500-507
-  else biloop_run<true>(lds, c, v, b.delta, lane);
+  if (pf >= -690 && pf <= 690) { // raccess.cpp:500-507
+    // large log Z: nearly always decided by the classification alone
+    if (pf < 120.0 || !biloop_classify(lds, c, v, b.delta, lane)) biloop_run<false>(lds, c, v, b.delta, lane);
+  } else {
+    biloop_run<true>(lds, c, v, b.delta, lane);
+  }
 }
 
 // ---------------------------------------------------------------------- accessibility

@@ -61,3 +61,20 @@ def test_batch_order_and_chunking_do_not_matter(ctx, oracle):
         oa, oc = oracle.raccess(s, 70, 5) if len(s) else (np.zeros(0, np.float32), np.zeros(0, np.float32))
         assert np.array_equal(bits(acc), bits(oa)), len(s)
         assert np.array_equal(bits(cond), bits(oc)), len(s)
+
+
+def test_lengths_around_the_overflow_classification(ctx, oracle):
+    """The bulge/interior sums of long sequences are classified (overflow / zero) instead of summed
+    (raccess_kernels.hip: biloop_classify) once log Z >= 120; below that, and whenever some position
+    cannot be decided that way, the ordered sums are used.  Lengths on both sides of the switch,
+    AU-rich (small log Z per nucleotide) and GC-rich (large), against the oracle."""
+    rng = np.random.default_rng(11)
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in (380, 430, 470, 520, 600, 760)]
+    seqs.append("".join(rng.choice(list("ACGU"), 900, p=[0.4, 0.1, 0.1, 0.4])))
+    seqs.append("".join(rng.choice(list("ACGU"), 500, p=[0.15, 0.35, 0.35, 0.15])))
+    seqs.append("A" * 300 + "".join(rng.choice(list("ACGU"), 400)) + "U" * 300)  # positions without any loop term
+    res = ctx.accessibility(seqs, 70, 5)
+    for s, (acc, cond) in zip(seqs, res):
+        oa, oc = oracle.raccess(s, 70, 5)
+        assert np.array_equal(bits(acc), bits(oa)), len(s)
+        assert np.array_equal(bits(cond), bits(oc)), len(s)
