@@ -970,6 +970,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     }
     return PRB_OK;
   };
+  PRB_HIP(hipMemsetAsync(w.tierOf.p, 0, (size_t)nung, ctx->stream)); // no hit carries a resume mark yet
   static const char *const kTierTimer[4] = {"gapped", "gapped_t1", "gapped_t2", "gapped_slow"};
   {
     const uint32_t *cur = nullptr; // all of U

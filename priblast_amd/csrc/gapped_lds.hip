@@ -222,7 +222,11 @@ struct HitCtx {
   int query, id, qn;
   int diag_q, diag_d, diag_len, ndiag, nleft, nright;
   bool unsorted, ovf;
+  bool resumed; // direction 0 was completed by an earlier kernel of the cascade: start at direction 1
 };
+// tier_out[x] of a hit that outgrew a kernel in direction 1: out.*[x] and bp_count[x] hold its state
+// after direction 0, so the next kernel of the cascade only has to extend the other direction
+constexpr uint8_t kResumeMark = 0x40;
 
 // The scalars of one direction's recurrence (kept redundantly in every lane of the group).
 struct DirState {
@@ -611,6 +615,19 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
   c.ovf = false;
   c.nleft = 0;
   c.nright = 0;
+  c.resumed = false;
+  if (kMode == 0 && a.tier_out[x] == kResumeMark) {
+    h.q_sp = a.out.q_sp[x];
+    h.db_sp = a.out.db_sp[x];
+    h.q_len = a.out.q_len[x];
+    h.db_len = a.out.db_len[x];
+    h.id_start = a.out.db_id_start[x];
+    h.e_tot = a.out.e_tot[x];
+    h.e_acc = a.out.e_acc[x];
+    h.e_hyb = a.out.e_hyb[x];
+    c.nleft = a.bp_count[x] & 0xFFFF;
+    c.resumed = true;
+  }
 }
 
 // After a direction: traceback (:300-308, :409-424) from the arg-min cell through the
@@ -653,13 +670,27 @@ __device__ __forceinline__ void hit_dir_done(const GapArgs &a, HitCtx &c, int fl
 }
 
 // After both directions (or an overflow): lane 0 of the group writes the results of hit w.
-template <int kMode> __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const HitCtx &c, int gl) {
+template <int kMode>
+__device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const HitCtx &c, int flag /* last direction run */, int gl) {
   if (gl != 0) return;
   const SearchConst &sc = a.sc;
   const HitState &h = c.h;
   const uint8_t *ds = a.pg.seqs;
   if (kMode == 0) {
     a.overflow[w] = c.ovf ? 1 : 0;
+    if (c.ovf && flag == 1) { // direction 0 is done (c.h is its result): leave it for the next kernel
+      const int64_t x = c.x;
+      a.out.q_sp[x] = h.q_sp;
+      a.out.db_sp[x] = h.db_sp;
+      a.out.q_len[x] = h.q_len;
+      a.out.db_len[x] = h.db_len;
+      a.out.db_id_start[x] = h.id_start;
+      a.out.e_acc[x] = h.e_acc;
+      a.out.e_hyb[x] = h.e_hyb;
+      a.out.e_tot[x] = h.e_tot;
+      a.bp_count[x] = c.nleft;
+      a.tier_out[x] = kResumeMark;
+    }
     if (!c.ovf) {
       const int64_t x = c.x;
       a.tier_out[x] = (uint8_t)a.tier_id;
@@ -743,12 +774,13 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
     GP_MARK(14);
     if (tick == 0) {
       if (phase == kFinished) {
-        const DirResult r = dir_finish(d, c.h, flag);
+        DirResult r{true, 0};
+        if (!d.overflow) r = dir_finish(d, c.h, flag); // an overflowed direction leaves c.h as it was
         hit_dir_done<kMode, true>(a, c, flag, d, r, S, gl);
         group_sync<true>();
         GP_MARK(7);
         if (c.ovf || flag == 1) {
-          hit_store<kMode>(a, w, c, gl);
+          hit_store<kMode>(a, w, c, flag, gl);
           unsigned long long nw = 0;
           if (gl == 0) nw = (unsigned long long)ngroups + atomicAdd(a.next_work, 1ull);
           w = (int64_t)__shfl(nw, gbase);
@@ -761,7 +793,7 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
       }
       if (phase == kLoad) {
         hit_load<kMode>(a, w, c);
-        flag = 0;
+        flag = c.resumed ? 1 : 0;
         phase = kInit;
         GP_MARK(8);
       }
@@ -798,18 +830,21 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
   DirState d;
   for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) {
     hit_load<kMode>(a, w, c);
-    for (int flag = 0; flag < 2 && !c.ovf; flag++) {
+    int last = 0;
+    for (int flag = c.resumed ? 1 : 0; flag < 2 && !c.ovf; flag++) {
       GP_MARK(8);
       dir_init<64, false>(a.sc, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
       GP_MARK(0);
       while (!dir_step<64, false>(a.sc, a.o, c, flag, S, gl, 0, d, prof)) {
       }
-      const DirResult r = dir_finish(d, c.h, flag);
+      DirResult r{true, 0};
+      if (!d.overflow) r = dir_finish(d, c.h, flag);
       hit_dir_done<kMode, false>(a, c, flag, d, r, S, gl);
       group_sync<false>();
+      last = flag;
       GP_MARK(7);
     }
-    hit_store<kMode>(a, w, c, gl);
+    hit_store<kMode>(a, w, c, last, gl);
     GP_MARK(9);
   }
   prof.flush(3 * 2 + (kMode != 0));
