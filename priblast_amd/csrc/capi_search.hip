@@ -69,12 +69,12 @@ struct PinnedBuf {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumeCount;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumeCount})
       b->release();
     pinned.release();
     cand_pinned.release();
@@ -971,6 +971,19 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     return PRB_OK;
   };
   PRB_HIP(hipMemsetAsync(w.tierOf.p, 0, (size_t)nung, ctx->stream)); // no hit carries a resume mark yet
+  // state dumps for the hits that outgrow tier 0 (~4 %): room for one hit in eight, at most 2 M
+  GapResume rs{nullptr, nullptr, nullptr, 0};
+  if (!getenv("PRB_GAPPED_NO_RESUME")) {
+    rs.cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
+    if ((rc = w.resumeSlot.ensure((size_t)nung * 4)) || (rc = w.resumePool.ensure((size_t)rs.cap * gapped_resume_bytes())))
+      return rc;
+    rs.slot = w.resumeSlot.as<int32_t>();
+    rs.pool = w.resumePool.as<uint8_t>();
+    if ((rc = w.resumeCount.ensure(16))) return rc;
+    rs.count = w.resumeCount.as<uint32_t>();
+    PRB_HIP(hipMemsetAsync(rs.count, 0, 4, ctx->stream));
+    PRB_HIP(hipMemsetAsync(rs.slot, 0xFF, (size_t)nung * 4, ctx->stream));
+  }
   static const char *const kTierTimer[4] = {"gapped", "gapped_t1", "gapped_t2", "gapped_slow"};
   {
     const uint32_t *cur = nullptr; // all of U
@@ -988,7 +1001,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                   w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
-                                  w.count.as<unsigned long long>() + 1, ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, rs, ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
         cur = bufs[nb];
@@ -1082,7 +1095,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,
                                   w.first.as<uint8_t>(), nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
-                                  w.count.as<unsigned long long>() + 1, ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, GapResume{nullptr, nullptr, nullptr, 0}, ctx->stream));
       }
       PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are reused by the next tier
     }

@@ -66,12 +66,16 @@ constexpr int kInitStage = 16; // extension lengths whose accessibility sums dir
 // workgroup, staged extension lengths (<= lanes per hit)
 struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
   static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by tier 1
+  static constexpr bool kResumes = false;
 };
 struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
   static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr bool kResumable = false, kResumes = true; // continues the state dumps of tier 0
 };
 struct Tier2 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
   static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
+  static constexpr bool kResumable = false, kResumes = false;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -128,6 +132,7 @@ template <class T, class Rec> struct LdsState {
 };
 template <class T, class Rec> struct LdsStore {
   using R = Rec;
+  static constexpr bool kResumable = T::kResumable;
   LdsState<T, Rec> &s;
   __device__ __forceinline__ int cap_d() const { return T::kCapD; }
   __device__ __forceinline__ int cap_r() const { return T::kCapR; }
@@ -143,6 +148,7 @@ template <class T, class Rec> struct LdsStore {
 };
 struct HbmStore { // one block of the scratch per group
   using R = Rec64;
+  static constexpr bool kResumable = false;
   double *eq_, *ed_, *hyb_;
   uint64_t *info_;
   uint8_t *ptab_, *qb_, *db_;
@@ -235,6 +241,10 @@ struct DirState {
   int64_t db_start, min_db_start;
   int q_start, id_start, id_end, min_q_start, q_length, db_length, min_q_len, min_db_len, min_id_start;
   int length, min_length, best, nrec, lo, tq0, td0;
+  int staged; // eq[] / ed[] are computed for the extension lengths 1..staged
+  // set when a resumable kernel runs out of cells in the middle of an anti-diagonal: the chunk to
+  // go on with, and the end of the candidate window of that anti-diagonal (0: not in the middle)
+  int resume_i0, resume_dstart;
   bool overflow;
 };
 
@@ -304,6 +314,41 @@ __device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, 
       S.ed(len - 1) = v;
     }
   }
+  d.staged = L0 + nb - 1 < S.cap_d() ? L0 + nb - 1 : S.cap_d();
+  group_sync<kLds>();
+}
+
+// Bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407); the
+// first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154).
+// Also clears the three predecessor-type rows.
+template <int G, bool kLds, class Store>
+__device__ __forceinline__ void stage_windows(const HitCtx &c, int flag, const uint8_t *ds, int64_t dn, const Store &S, int gl,
+                                              DirState &d, bool clear_rows = true) {
+  const uint8_t *qs = c.qs;
+  const int qn = c.qn;
+  const int wn = S.win_len();
+  d.tq0 = wn;
+  d.td0 = wn;
+  for (int t = gl; t < wn; t += G) {
+    const int64_t qp = flag == 0 ? (int64_t)d.q_start - t : (int64_t)d.q_start + t;
+    const int64_t dp = flag == 0 ? d.db_start - t : d.db_start + t;
+    const int qc = (qp >= 0 && qp < qn) ? get_char(qs, qp) : 0;
+    const int dc = (dp >= 0 && dp < dn) ? get_char(ds, dp) : 0;
+    S.qb(t) = (uint8_t)qc;
+    S.db(t) = (uint8_t)dc;
+    if (t >= 1 && qc == 0 && t < d.tq0) d.tq0 = t;
+    if (t >= 1 && dc == 0 && t < d.td0) d.td0 = t;
+  }
+  if (clear_rows) {
+    uint32_t *pz = reinterpret_cast<uint32_t *>(&S.ptab(0, 0)); // 3 rows, each a multiple of 4 bytes
+    for (int t = gl; t < 3 * S.ptab_len() / 4; t += G) pz[t] = 0;
+  }
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) {
+    const int ta = __shfl_xor(d.tq0, m), tb = __shfl_xor(d.td0, m);
+    d.tq0 = ta < d.tq0 ? ta : d.tq0;
+    d.td0 = tb < d.td0 ? tb : d.td0;
+  }
   group_sync<kLds>();
 }
 
@@ -317,8 +362,6 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
                                          const Store &S, int gl, int delta, DirState &d) {
   using R = typename Store::R;
   const HitState &h = c.h;
-  const uint8_t *qs = c.qs;
-  const int qn = c.qn;
   d.min_e = h.e_tot;
   d.first_a = h.e_acc;
   d.min_a = d.first_a;
@@ -342,33 +385,10 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
   d.min_length = 0;
   d.best = 0;
   d.overflow = false;
+  d.resume_i0 = 0;
+  d.resume_dstart = 0;
 
-  // bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407);
-  // the first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154)
-  const int wn = S.win_len();
-  d.tq0 = wn;
-  d.td0 = wn;
-  for (int t = gl; t < wn; t += G) {
-    const int64_t qp = flag == 0 ? (int64_t)d.q_start - t : (int64_t)d.q_start + t;
-    const int64_t dp = flag == 0 ? d.db_start - t : d.db_start + t;
-    const int qc = (qp >= 0 && qp < qn) ? get_char(qs, qp) : 0;
-    const int dc = (dp >= 0 && dp < dn) ? get_char(ds, dp) : 0;
-    S.qb(t) = (uint8_t)qc;
-    S.db(t) = (uint8_t)dc;
-    if (t >= 1 && qc == 0 && t < d.tq0) d.tq0 = t;
-    if (t >= 1 && dc == 0 && t < d.td0) d.td0 = t;
-  }
-  {
-    uint32_t *pz = reinterpret_cast<uint32_t *>(&S.ptab(0, 0)); // 3 rows, each a multiple of 4 bytes
-    for (int t = gl; t < 3 * S.ptab_len() / 4; t += G) pz[t] = 0;
-  }
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) {
-    const int ta = __shfl_xor(d.tq0, m), tb = __shfl_xor(d.td0, m);
-    d.tq0 = ta < d.tq0 ? ta : d.tq0;
-    d.td0 = tb < d.td0 ? tb : d.td0;
-  }
-  group_sync<kLds>();
+  stage_windows<G, kLds>(c, flag, ds, dn, S, gl, d);
   // accessibility sums of the first kInitStage lengths (nearly every direction ends within them);
   // the cell list is still empty, so its energies' storage serves as the float scratch
   d.acc_prev = 0;
@@ -394,36 +414,41 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
   using R = typename Store::R;
   const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
   const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
-  d.length++;
-  if (d.length > S.cap_d()) {
-    d.overflow = true;
-    return true;
+  const bool mid = d.resume_i0 != 0; // continuing an anti-diagonal that a smaller kernel could not finish
+  if (!mid) {
+    if (d.length >= S.cap_d()) { // no room for another anti-diagonal: the state stays that of the last complete one
+      d.overflow = true;
+      return true;
+    }
+    d.length++;
   }
   // max_q_extension / max_db_extension as the reference has them after its checks at this d.length
   const bool q_open = d.length < d.tq0, d_open = d.length < d.td0;
   const int max_q = q_open ? 100000 : d.tq0 - 1, max_d = d_open ? 100000 : d.td0 - 1;
-  // cumulative accessibility change beyond the lengths dir_init prepared (one direction in ten
-  // gets here): lanes 0 / 1 read the terms straight from HBM
-  if ((d.length - 1) % kInitStage == 0 && d.length > kInitStage)
-    stage_acc<G, kLds>(c, flag, delta, S, gl, d, d.length, kInitStage, (float *)nullptr);
-  GP_MARK(1);
-  GP_COUNT(10);
   const int cur = d.length % 3, d2 = (d.length + 1) % 3; // d2 = (d.length - 2) mod 3
-  // recycle the row of anti-diagonal d.length-3 for this one
-  for (int t = gl; t <= d.length; t += G) S.ptab(cur, t) = 0;
-  group_sync<kLds>();
-  // prune candidates with d.length - first - second - 2 > drop (:213-217): a prefix of the list
-  if (d.length - 2 > drop) {
-    while (d.lo < d.nrec) {
-      const auto v = S.info(d.lo);
-      if (d.length - R::i(v) - R::j(v) - 2 > drop) d.lo++;
-      else break;
+  if (!mid) {
+    // cumulative accessibility change beyond the lengths prepared so far (one direction in ten gets
+    // here): lanes 0 / 1 read the terms straight from HBM
+    if (d.length > d.staged) stage_acc<G, kLds>(c, flag, delta, S, gl, d, d.length, kInitStage, (float *)nullptr);
+    GP_MARK(1);
+    GP_COUNT(10);
+    // recycle the row of anti-diagonal d.length-3 for this one
+    for (int t = gl; t <= d.length; t += G) S.ptab(cur, t) = 0;
+    group_sync<kLds>();
+    // prune candidates with d.length - first - second - 2 > drop (:213-217): a prefix of the list
+    if (d.length - 2 > drop) {
+      while (d.lo < d.nrec) {
+        const auto v = S.info(d.lo);
+        if (d.length - R::i(v) - R::j(v) - 2 > drop) d.lo++;
+        else break;
+      }
     }
   }
   GP_MARK(2);
-  const int dstart = d.nrec;
-  const int i_lo = d.length - max_d > 1 ? d.length - max_d : 1;
+  const int dstart = mid ? d.resume_dstart : d.nrec;
+  const int i_lo = mid ? d.resume_i0 : (d.length - max_d > 1 ? d.length - max_d : 1);
   const int i_hi = max_q < d.length - 1 ? max_q : d.length - 1;
+  d.resume_i0 = 0;
   for (int i0 = i_lo; i0 <= i_hi && !d.overflow; i0 += G) {
     const int i = i0 + gl, j = d.length - i;
     int type1 = 0;
@@ -452,6 +477,12 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
     if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
     GP_MARK(3);
     GP_COUNT(11);
+    if (Store::kResumable && d.nrec + __popcll(vmask) > S.cap_r()) { // out of cells: stop in front of this chunk
+      d.overflow = true;
+      d.resume_i0 = i0;
+      d.resume_dstart = dstart;
+      break;
+    }
     while (vmask) { // filled cells of this chunk, ascending i
       GP_COUNT(12);
       const int b = __builtin_ctzll(vmask);
@@ -574,7 +605,77 @@ struct GapArgs {
   const int64_t *bp_off;
   int32_t *bp_out;
   unsigned long long *next_work; // LDS kernels: work counter (zero at launch) behind the statically assigned first hits
+  // mode 0: state dumps of hits that outgrew tier 0, for tier 1 to continue from (resume_slot[x] = -1: none)
+  int32_t *resume_slot;
+  uint8_t *resume_pool;
+  uint32_t *resume_count;
+  int32_t resume_cap;
 };
+
+// A state dump: everything tier 1 needs to go on where tier 0 ran out of capacity.
+struct ResumeHeader {
+  DirState d;       // lane 0's copy, as of the last complete anti-diagonal
+  double acc_prev1; // lane 1's accumulator (the db-side chain)
+  HitState h;       // the hit as the running direction found it
+  int32_t flag, nleft;
+};
+using Tier0State = LdsState<Tier0, Rec32>;
+constexpr size_t kResumeBytes = (sizeof(ResumeHeader) + sizeof(Tier0State) + 63) & ~(size_t)63;
+
+template <int G>
+__device__ __forceinline__ void resume_dump(const GapArgs &a, const HitCtx &c, const DirState &d, int flag, const Tier0State &st,
+                                            int gl, int gbase) {
+  int slot = -1;
+  if (gl == 0) {
+    slot = (int)atomicAdd(a.resume_count, 1u);
+    if (slot >= a.resume_cap) slot = -1;
+  }
+  slot = __shfl(slot, gbase);
+  if (slot < 0) return;
+  uint8_t *dst = a.resume_pool + (size_t)slot * kResumeBytes;
+  ResumeHeader *H = reinterpret_cast<ResumeHeader *>(dst);
+  if (gl == 0) {
+    H->d = d;
+    H->h = c.h;
+    H->flag = flag;
+    H->nleft = c.nleft;
+    a.resume_slot[c.x] = slot;
+  } else if (gl == 1) {
+    H->acc_prev1 = d.acc_prev;
+  }
+  uint32_t *w = reinterpret_cast<uint32_t *>(dst + sizeof(ResumeHeader));
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&st);
+  for (int t = gl; t < (int)(sizeof(Tier0State) / 4); t += G) w[t] = src[t];
+}
+
+// Tier 1 side: the group's LDS state and scalars from a dump (its own, longer windows are staged afresh).
+template <int G, class Store>
+__device__ __forceinline__ void resume_load(const GapArgs &a, int slot, HitCtx &c, DirState &d, int &flag, const Store &S,
+                                            int gl) {
+  const uint8_t *src = a.resume_pool + (size_t)slot * kResumeBytes;
+  const ResumeHeader *H = reinterpret_cast<const ResumeHeader *>(src);
+  d = H->d;
+  if (gl == 1) d.acc_prev = H->acc_prev1;
+  d.overflow = false;
+  c.h = H->h;
+  c.nleft = H->nleft;
+  flag = H->flag;
+  const Tier0State *s0 = reinterpret_cast<const Tier0State *>(src + sizeof(ResumeHeader));
+  stage_windows<G, true>(c, flag, a.pg.seqs, a.pg.nchars, S, gl, d); // also clears the rows
+  for (int t = gl; t < Tier0::kCapD; t += G) {
+    S.eq(t) = s0->eq[t];
+    S.ed(t) = s0->ed[t];
+  }
+  for (int t = gl; t < d.nrec; t += G) {
+    S.hyb(t) = s0->hyb[t];
+    S.info(t) = s0->info[t];
+  }
+  for (int t = gl; t < 3 * (Tier0::kCapD + 4); t += G) {
+    const int row = t / (Tier0::kCapD + 4), i = t - row * (Tier0::kCapD + 4);
+    S.ptab(row, i) = s0->ptab[row][i];
+  }
+  group_sync<true>();
+}
 
 // Hit w of the work list.  kMode 0: extend, write the hit to out, the number of traced-back
 // pairs to bp_count[x] and the traced cells to the trace slot; 2: write the base pairs of the
@@ -775,7 +876,12 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
     if (tick == 0) {
       if (phase == kFinished) {
         DirResult r{true, 0};
-        if (!d.overflow) r = dir_finish(d, c.h, flag); // an overflowed direction leaves c.h as it was
+        if (!d.overflow) {
+          r = dir_finish(d, c.h, flag); // (an overflowed direction leaves c.h as it was)
+        } else {
+          if constexpr (kMode == 0 && T::kResumable)
+            if (a.resume_slot) resume_dump<G>(a, c, d, flag, lds[gid], gl, gbase);
+        }
         hit_dir_done<kMode, true>(a, c, flag, d, r, S, gl);
         group_sync<true>();
         GP_MARK(7);
@@ -795,6 +901,13 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
         hit_load<kMode>(a, w, c);
         flag = c.resumed ? 1 : 0;
         phase = kInit;
+        if constexpr (kMode == 0 && T::kResumes) {
+          const int slot = a.resume_slot ? a.resume_slot[c.x] : -1;
+          if (slot >= 0) {
+            resume_load<G>(a, slot, c, d, flag, S, gl);
+            phase = kRun;
+          }
+        }
         GP_MARK(8);
       }
       if (phase == kInit) {
@@ -864,6 +977,8 @@ extern "C" int prb_debug_gap_profile(unsigned long long *out, int reset) {
 }
 #endif
 
+size_t gapped_resume_bytes() { return kResumeBytes; }
+
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
   size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 4) + 2 * ((size_t)cap_diag + 16);
   return (b + 255) & ~(size_t)255;
@@ -883,9 +998,11 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
-                             const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, hipStream_t s) {
+                             const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, const GapResume &rs,
+                             hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, tier, first_flag, bp_count, trace, bp_off, bp_out, next_work};
+  GapArgs a{in,      out,   n,      subset, qb,        pg,         sc, o, overflow, tier_out, tier, first_flag, bp_count,
+            trace,   bp_off, bp_out, next_work, rs.slot, rs.pool, rs.count, rs.cap};
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
   return launch_tier<Tier2, Rec32W>(a, mode, s);
@@ -896,7 +1013,8 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
                               const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in, out, n, subset, qb, pg, sc, o, overflow, tier_out, 3, first_flag, bp_count, nullptr, bp_off, bp_out, nullptr};
+  GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, 3, first_flag, bp_count,
+            nullptr, bp_off, bp_out, nullptr, nullptr, nullptr, nullptr, 0};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
   else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);

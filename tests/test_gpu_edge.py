@@ -124,6 +124,11 @@ def test_results_do_not_depend_on_batch_composition(ctx, golden_dir, monkeypatch
         monkeypatch.setenv("PRB_SEARCH_PAIRS", "20000")
         assert run(seqs) == full
         monkeypatch.delenv("PRB_SEARCH_PAIRS")
+        # extensions that outgrow the first gapped kernel are continued from a state dump by the
+        # next one; without the dumps they are redone from scratch - same results
+        monkeypatch.setenv("PRB_GAPPED_NO_RESUME", "1")
+        assert run(seqs) == full
+        monkeypatch.delenv("PRB_GAPPED_NO_RESUME")
         for q in (0, 17, 63):
             assert run([seqs[q]])[0] == full[q]
     finally:
