@@ -318,6 +318,70 @@ __device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, 
   group_sync<kLds>();
 }
 
+// The same for the lengths beyond what dir_init prepared (one direction in ten gets here), when the
+// cell list is in use and cannot serve as scratch: every lane fetches the terms of its lengths into
+// registers (all loads in flight together), then the group walks the 16 lengths in order, the
+// terms coming from their lanes by shuffle; every lane carries both running sums.
+template <int G, bool kLds, class Store>
+__device__ __forceinline__ void stage_acc_regs(const HitCtx &c, int flag, int delta, const Store &S, int gl, int gbase,
+                                               DirState &d, int L0) {
+  constexpr int nb = kInitStage, per = (nb + G - 1) / G;
+  const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
+  float t0[per], t1[per], t2[per], t3[per]; // flag 0: query acc, acc+1, cond | db cond;  flag 1: query cond | db acc, acc+1, cond
+#pragma unroll
+  for (int r = 0; r < per; r++) {
+    t0[r] = t1[r] = t2[r] = t3[r] = 0.0f;
+    const int t = gl + r * G, len = L0 + t;
+    if (t < nb) {
+      if (len < d.tq0) {
+        if (flag == 0) {
+          const int p = d.q_start - len;
+          t0[r] = qacc[p];
+          t1[r] = qacc[p + 1];
+          t2[r] = qcond[p + delta];
+        } else {
+          t0[r] = qcond[d.q_start + len];
+        }
+      }
+      if (len < d.td0) {
+        if (flag == 0) {
+          t3[r] = dcond[d.id_end + len];
+        } else {
+          const int p = d.id_start - len;
+          t1[r] = dacc[p];
+          t2[r] = dacc[p + 1];
+          t3[r] = dcond[p + delta];
+        }
+      }
+    }
+  }
+  double veq = __shfl(d.acc_prev, gbase), ved = __shfl(d.acc_prev, gbase + (G > 1 ? 1 : 0));
+#pragma unroll
+  for (int k = 0; k < nb; k++) {
+    const int src = gbase + (k % G), r = k / G, len = L0 + k;
+    const float a0 = __shfl(t0[r], src), a1 = __shfl(t1[r], src), a2 = __shfl(t2[r], src), a3 = __shfl(t3[r], src);
+    if (len <= S.cap_d()) {
+      if (len < d.tq0) {
+        double v;
+        if (flag == 0) v = len == 1 ? (double)(a0 - a1 + a2) : veq + a0 - a1 + a2; // float arithmetic at len 1, as the reference
+        else v = len == 1 ? (double)a0 : veq + a0;
+        veq = v;
+        if (gl == 0) S.eq(len - 1) = v;
+      }
+      if (len < d.td0) {
+        double v;
+        if (flag == 0) v = len == 1 ? (double)a3 : ved + a3;
+        else v = len == 1 ? (double)(a1 - a2 + a3) : ved + a1 - a2 + a3;
+        ved = v;
+        if (gl == 0) S.ed(len - 1) = v;
+      }
+    }
+  }
+  d.acc_prev = (G > 1 && gl == 1) ? ved : veq;
+  d.staged = L0 + nb - 1 < S.cap_d() ? L0 + nb - 1 : S.cap_d();
+  group_sync<kLds>();
+}
+
 // Bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407); the
 // first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154).
 // Also clears the three predecessor-type rows.
@@ -427,9 +491,8 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
   const int max_q = q_open ? 100000 : d.tq0 - 1, max_d = d_open ? 100000 : d.td0 - 1;
   const int cur = d.length % 3, d2 = (d.length + 1) % 3; // d2 = (d.length - 2) mod 3
   if (!mid) {
-    // cumulative accessibility change beyond the lengths prepared so far (one direction in ten gets
-    // here): lanes 0 / 1 read the terms straight from HBM
-    if (d.length > d.staged) stage_acc<G, kLds>(c, flag, delta, S, gl, d, d.length, kInitStage, (float *)nullptr);
+    // cumulative accessibility change beyond the lengths prepared so far (one direction in ten gets here)
+    if (d.length > d.staged) stage_acc_regs<G, kLds>(c, flag, delta, S, gl, gbase, d, d.length);
     GP_MARK(1);
     GP_COUNT(10);
     // recycle the row of anti-diagonal d.length-3 for this one
