@@ -27,12 +27,13 @@ def _worker(rank, world, store, q):
         hits["e_tot"] = -8.5 - rank
         hits["query"] = rank
         got = pdist.gather_hits(hits)
+        got_list = got.tolist() if rank == 0 else None  # the result is a view of a buffer the next gather reuses
         n2 = 3 + rank
         h2 = np.zeros(n2, capi.HIT_DTYPE)
         h2["db_sp"] = 1000 * rank + np.arange(n2)
         got2 = pdist.gather_hits(h2)
         if rank == 0:
-            q.put((covered, got.tolist(), got2["db_sp"].tolist()))
+            q.put((covered, got_list, got2["db_sp"].tolist()))
         else:
             assert got is None and got2 is None
             q.put((covered, None, None))

@@ -133,3 +133,35 @@ def test_results_do_not_depend_on_batch_composition(ctx, golden_dir, monkeypatch
             assert run([seqs[q]])[0] == full[q]
     finally:
         db.close()
+
+
+_GATHER_SCRIPT = """
+import sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[2])
+from priblast_amd import capi, dist as pdist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="file://" + sys.argv[1], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+hits = np.zeros(300_000, capi.HIT_DTYPE)
+hits["q_sp"] = np.arange(len(hits))
+hits["e_tot"] = -8.0 - np.arange(len(hits)) * 1e-6
+got = pdist.gather_hits(hits, 0, "cuda")
+assert got.dtype == capi.HIT_DTYPE and np.array_equal(got, hits)
+assert len(pdist.gather_hits(hits[:0], 0, "cuda")) == 0
+dist.destroy_process_group()
+print("gather ok")
+"""
+
+
+def test_final_gather_on_the_gpu_backend(tmp_path):
+    """The RCCL path of the final hit gather (device buffers, pinned root buffer) with the one rank
+    this box has, in a process of its own (torch has to initialise the GPU before the library
+    does); the two-rank logic is covered on CPU by tests/test_dist_gloo.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT, str(tmp_path / "rdv"), root], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "gather ok" in r.stdout, r.stderr[-2000:]
