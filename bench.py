@@ -179,7 +179,8 @@ def main():
         wall["qbatch (encode + SA + upload)"] += t1 - t0
         wall["accessibility"] += t2 - t1
         wall["search (DFS + GPU stages + download)"] += t3 - t2
-        hits = np.concatenate(allhits) if allhits else np.zeros(0, capi.HIT_DTYPE)
+        # (views of the library's hit sets; only a multi-page database needs them joined)
+        hits = allhits[0] if len(allhits) == 1 else (np.concatenate(allhits) if allhits else np.zeros(0, capi.HIT_DTYPE))
         if world > 1:  # final hit gather over RCCL: counts, then padded POD records
             pdist.gather_hits(hits, 0, "cuda")
         return total
