@@ -1205,7 +1205,7 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   Drainer drain(&hs->hits, &hs->bp, wsp.pin_hits, wsp.pin_bp);
   hs->drain = &drain;
   const char *env = getenv("PRB_SEARCH_PAIRS");
-  const double budget = env ? atof(env) : 1.2e8;
+  const double budget = env ? atof(env) : 4.0e8;
   int rc = drain.start();
   double wait_ms = 0;
   std::vector<int64_t> cbase, rbase, ebase;
