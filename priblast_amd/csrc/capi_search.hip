@@ -69,12 +69,12 @@ struct PinnedBuf {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumeCount;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumeCount;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumeCount})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumeCount})
       b->release();
     pinned.release();
     cand_pinned.release();
@@ -971,18 +971,25 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     return PRB_OK;
   };
   PRB_HIP(hipMemsetAsync(w.tierOf.p, 0, (size_t)nung, ctx->stream)); // no hit carries a resume mark yet
-  // state dumps for the hits that outgrow tier 0 (~4 %): room for one hit in eight, at most 2 M
-  GapResume rs{nullptr, nullptr, nullptr, 0};
+  // state dumps for the hits that outgrow tier 0 (~4 %: room for one hit in eight, at most 2 M) and
+  // tier 1 (~0.7 %: one in 32, at most 1 M)
+  const GapResume no_resume{nullptr, nullptr, nullptr, 0};
+  GapResume rs[2] = {no_resume, no_resume};
   if (!getenv("PRB_GAPPED_NO_RESUME")) {
-    rs.cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
-    if ((rc = w.resumeSlot.ensure((size_t)nung * 4)) || (rc = w.resumePool.ensure((size_t)rs.cap * gapped_resume_bytes())))
+    rs[0].cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
+    rs[1].cap = (int32_t)std::min<int64_t>(nung / 32 + 1024, 1 << 20);
+    if ((rc = w.resumeSlot.ensure((size_t)nung * 8)) || (rc = w.resumeCount.ensure(16)) ||
+        (rc = w.resumePool.ensure((size_t)rs[0].cap * gapped_resume_bytes(0))) ||
+        (rc = w.resumePool2.ensure((size_t)rs[1].cap * gapped_resume_bytes(1))))
       return rc;
-    rs.slot = w.resumeSlot.as<int32_t>();
-    rs.pool = w.resumePool.as<uint8_t>();
-    if ((rc = w.resumeCount.ensure(16))) return rc;
-    rs.count = w.resumeCount.as<uint32_t>();
-    PRB_HIP(hipMemsetAsync(rs.count, 0, 4, ctx->stream));
-    PRB_HIP(hipMemsetAsync(rs.slot, 0xFF, (size_t)nung * 4, ctx->stream));
+    rs[0].slot = w.resumeSlot.as<int32_t>();
+    rs[1].slot = w.resumeSlot.as<int32_t>() + nung;
+    rs[0].pool = w.resumePool.as<uint8_t>();
+    rs[1].pool = w.resumePool2.as<uint8_t>();
+    rs[0].count = w.resumeCount.as<uint32_t>();
+    rs[1].count = w.resumeCount.as<uint32_t>() + 1;
+    PRB_HIP(hipMemsetAsync(w.resumeCount.p, 0, 8, ctx->stream));
+    PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 8, ctx->stream));
   }
   static const char *const kTierTimer[4] = {"gapped", "gapped_t1", "gapped_t2", "gapped_slow"};
   {
@@ -1001,7 +1008,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                   w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
-                                  w.count.as<unsigned long long>() + 1, rs, ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, tier == 1 ? rs[0] : tier == 2 ? rs[1] : no_resume,
+                                  tier == 0 ? rs[0] : tier == 1 ? rs[1] : no_resume, ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
         cur = bufs[nb];
@@ -1095,7 +1103,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,
                                   w.first.as<uint8_t>(), nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
-                                  w.count.as<unsigned long long>() + 1, GapResume{nullptr, nullptr, nullptr, 0}, ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, GapResume{nullptr, nullptr, nullptr, 0},
+                                  GapResume{nullptr, nullptr, nullptr, 0}, ctx->stream));
       }
       PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are reused by the next tier
     }

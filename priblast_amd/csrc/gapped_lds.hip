@@ -64,6 +64,7 @@ namespace {
 constexpr int kInitStage = 16; // extension lengths whose accessibility sums dir_init prepares
 // LDS tiers: lanes per hit, (anti-diagonals, filled cells) per direction, groups (= hits) per
 // workgroup, staged extension lengths (<= lanes per hit)
+struct Rec32;
 struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
   static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
   static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by tier 1
@@ -71,11 +72,15 @@ struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
 };
 struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
   static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
-  static constexpr bool kResumable = false, kResumes = true; // continues the state dumps of tier 0
+  static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 0, leaves its own
+  using From = Tier0;
+  using FromRec = Rec32;
 };
 struct Tier2 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
   static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
-  static constexpr bool kResumable = false, kResumes = false;
+  static constexpr bool kResumable = false, kResumes = true; // continues the state dumps of tier 1
+  using From = Tier1;
+  using FromRec = Rec32;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -668,11 +673,9 @@ struct GapArgs {
   const int64_t *bp_off;
   int32_t *bp_out;
   unsigned long long *next_work; // LDS kernels: work counter (zero at launch) behind the statically assigned first hits
-  // mode 0: state dumps of hits that outgrew tier 0, for tier 1 to continue from (resume_slot[x] = -1: none)
-  int32_t *resume_slot;
-  uint8_t *resume_pool;
-  uint32_t *resume_count;
-  int32_t resume_cap;
+  // mode 0: state dumps of hits that outgrow an LDS tier, for the next one to continue from
+  // (slot[x] = -1: none): `rin` = what this kernel may continue, `rout` = where it leaves its own
+  GapResume rin, rout;
 };
 
 // A state dump: everything tier 1 needs to go on where tier 0 ran out of capacity.
@@ -682,59 +685,64 @@ struct ResumeHeader {
   HitState h;       // the hit as the running direction found it
   int32_t flag, nleft;
 };
-using Tier0State = LdsState<Tier0, Rec32>;
-constexpr size_t kResumeBytes = (sizeof(ResumeHeader) + sizeof(Tier0State) + 63) & ~(size_t)63;
+// slot size for dumps of tier T (tier 0 dumps are read by tier 1, tier 1 dumps by tier 2)
+template <class T, class Rec> constexpr size_t resume_bytes() {
+  return (sizeof(ResumeHeader) + sizeof(LdsState<T, Rec>) + 63) & ~(size_t)63;
+}
 
-template <int G>
-__device__ __forceinline__ void resume_dump(const GapArgs &a, const HitCtx &c, const DirState &d, int flag, const Tier0State &st,
-                                            int gl, int gbase) {
+template <int G, class T, class Rec>
+__device__ __forceinline__ void resume_dump(const GapResume &ro, const HitCtx &c, const DirState &d, int flag,
+                                            const LdsState<T, Rec> &st, int gl, int gbase) {
   int slot = -1;
   if (gl == 0) {
-    slot = (int)atomicAdd(a.resume_count, 1u);
-    if (slot >= a.resume_cap) slot = -1;
+    slot = (int)atomicAdd(ro.count, 1u);
+    if (slot >= ro.cap) slot = -1;
   }
   slot = __shfl(slot, gbase);
   if (slot < 0) return;
-  uint8_t *dst = a.resume_pool + (size_t)slot * kResumeBytes;
+  uint8_t *dst = ro.pool + (size_t)slot * resume_bytes<T, Rec>();
   ResumeHeader *H = reinterpret_cast<ResumeHeader *>(dst);
   if (gl == 0) {
     H->d = d;
     H->h = c.h;
     H->flag = flag;
     H->nleft = c.nleft;
-    a.resume_slot[c.x] = slot;
+    ro.slot[c.x] = slot;
   } else if (gl == 1) {
     H->acc_prev1 = d.acc_prev;
   }
   uint32_t *w = reinterpret_cast<uint32_t *>(dst + sizeof(ResumeHeader));
   const uint32_t *src = reinterpret_cast<const uint32_t *>(&st);
-  for (int t = gl; t < (int)(sizeof(Tier0State) / 4); t += G) w[t] = src[t];
+  for (int t = gl; t < (int)(sizeof(LdsState<T, Rec>) / 4); t += G) w[t] = src[t];
 }
 
-// Tier 1 side: the group's LDS state and scalars from a dump (its own, longer windows are staged afresh).
-template <int G, class Store>
-__device__ __forceinline__ void resume_load(const GapArgs &a, int slot, HitCtx &c, DirState &d, int &flag, const Store &S,
-                                            int gl) {
-  const uint8_t *src = a.resume_pool + (size_t)slot * kResumeBytes;
+// Receiving side: the group's LDS state and scalars from a dump of the smaller tier TS (its own,
+// longer windows are staged afresh; the cell records are re-packed when the formats differ).
+template <int G, class TS, class RecS, class Store>
+__device__ __forceinline__ void resume_load(const GapResume &ri, int slot, const GapArgs &a, HitCtx &c, DirState &d, int &flag,
+                                            const Store &S, int gl) {
+  using R = typename Store::R;
+  const uint8_t *src = ri.pool + (size_t)slot * resume_bytes<TS, RecS>();
   const ResumeHeader *H = reinterpret_cast<const ResumeHeader *>(src);
   d = H->d;
-  if (gl == 1) d.acc_prev = H->acc_prev1;
+  if (G > 1 && gl == 1) d.acc_prev = H->acc_prev1;
   d.overflow = false;
   c.h = H->h;
   c.nleft = H->nleft;
   flag = H->flag;
-  const Tier0State *s0 = reinterpret_cast<const Tier0State *>(src + sizeof(ResumeHeader));
+  const LdsState<TS, RecS> *s0 = reinterpret_cast<const LdsState<TS, RecS> *>(src + sizeof(ResumeHeader));
   stage_windows<G, true>(c, flag, a.pg.seqs, a.pg.nchars, S, gl, d); // also clears the rows
-  for (int t = gl; t < Tier0::kCapD; t += G) {
+  for (int t = gl; t < TS::kCapD; t += G) {
     S.eq(t) = s0->eq[t];
     S.ed(t) = s0->ed[t];
   }
   for (int t = gl; t < d.nrec; t += G) {
     S.hyb(t) = s0->hyb[t];
-    S.info(t) = s0->info[t];
+    const auto v = s0->info[t];
+    S.info(t) = R::pack(RecS::i(v), RecS::j(v), RecS::pred(v), RecS::type(v), RecS::qa(v), RecS::da(v));
   }
-  for (int t = gl; t < 3 * (Tier0::kCapD + 4); t += G) {
-    const int row = t / (Tier0::kCapD + 4), i = t - row * (Tier0::kCapD + 4);
+  for (int t = gl; t < 3 * (TS::kCapD + 4); t += G) {
+    const int row = t / (TS::kCapD + 4), i = t - row * (TS::kCapD + 4);
     S.ptab(row, i) = s0->ptab[row][i];
   }
   group_sync<true>();
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
           r = dir_finish(d, c.h, flag); // (an overflowed direction leaves c.h as it was)
         } else {
           if constexpr (kMode == 0 && T::kResumable)
-            if (a.resume_slot) resume_dump<G>(a, c, d, flag, lds[gid], gl, gbase);
+            if (a.rout.slot) resume_dump<G, T, Rec>(a.rout, c, d, flag, lds[gid], gl, gbase);
         }
         hit_dir_done<kMode, true>(a, c, flag, d, r, S, gl);
         group_sync<true>();
@@ -965,9 +973,9 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
         flag = c.resumed ? 1 : 0;
         phase = kInit;
         if constexpr (kMode == 0 && T::kResumes) {
-          const int slot = a.resume_slot ? a.resume_slot[c.x] : -1;
+          const int slot = a.rin.slot ? a.rin.slot[c.x] : -1;
           if (slot >= 0) {
-            resume_load<G>(a, slot, c, d, flag, S, gl);
+            resume_load<G, typename T::From, typename T::FromRec>(a.rin, slot, a, c, d, flag, S, gl);
             phase = kRun;
           }
         }
@@ -1040,7 +1048,7 @@ extern "C" int prb_debug_gap_profile(unsigned long long *out, int reset) {
 }
 #endif
 
-size_t gapped_resume_bytes() { return kResumeBytes; }
+size_t gapped_resume_bytes(int tier) { return tier == 0 ? resume_bytes<Tier0, Rec32>() : resume_bytes<Tier1, Rec32>(); }
 
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
   size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 4) + 2 * ((size_t)cap_diag + 16);
@@ -1061,11 +1069,11 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
 hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
-                             const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, const GapResume &rs,
-                             hipStream_t s) {
+                             const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, const GapResume &rin,
+                             const GapResume &rout, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,   n,      subset, qb,        pg,         sc, o, overflow, tier_out, tier, first_flag, bp_count,
-            trace,   bp_off, bp_out, next_work, rs.slot, rs.pool, rs.count, rs.cap};
+            trace,   bp_off, bp_out, next_work, rin,     rout};
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
   return launch_tier<Tier2, Rec32W>(a, mode, s);
@@ -1077,7 +1085,7 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
                               const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, 3, first_flag, bp_count,
-            nullptr, bp_off, bp_out, nullptr, nullptr, nullptr, nullptr, 0};
+            nullptr, bp_off, bp_out, nullptr, GapResume{nullptr, nullptr, nullptr, 0}, GapResume{nullptr, nullptr, nullptr, 0}};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
   else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);

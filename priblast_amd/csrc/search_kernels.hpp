@@ -138,16 +138,18 @@ struct GapScratch {
   int32_t nthreads;        // number of wavefronts (= grid size)
 };
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec);
-// State dumps of the hits that outgrow LDS tier 0 (mode 0): tier 1 continues from them instead of
-// starting over.  slot[x] = -1 or the hit's dump; pool = cap dumps of gapped_resume_bytes() each;
-// *count = dumps taken so far (zero it together with the slots).  All null / 0: no dumps.
+// State dumps of the hits that outgrow LDS tier 0 / tier 1 (mode 0): the next tier continues from
+// them instead of starting over.  slot[x] = -1 or the hit's dump; pool = cap dumps of
+// gapped_resume_bytes(tier that writes them) each; *count = dumps taken so far (zero it together
+// with the slots).  All null / 0: no dumps.  A launch gets the pool it may continue (rin: tier 1
+// <- tier 0's, tier 2 <- tier 1's) and the pool it fills (rout: tiers 0 and 1).
 struct GapResume {
   int32_t *slot;
   uint8_t *pool;
   uint32_t *count;
   int32_t cap;
 };
-size_t gapped_resume_bytes();
+size_t gapped_resume_bytes(int tier);
 // Gapped extension (gapped_lds.hip).  mode 0: extend hits (coords + energies) into `out`,
 // overflow[i] = 1 if the state capacity was too small, bp_count[x] = pairs traced back by the
 // two extensions of hit x; mode 2: write the base pairs of list entry i at bp_off[i] (hits
@@ -160,7 +162,7 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
                              const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work /* 8 bytes of scratch */,
-                             const GapResume &rs, hipStream_t s);
+                             const GapResume &rin, const GapResume &rout, hipStream_t s);
 // Trace slots: the extension pass (mode 0, LDS tiers) leaves the first kTraceCap cells (i | j << 8)
 // of each direction's traceback chain of hit x at trace[(2x + direction) * kTraceCap ...];
 // launch_bp_expand writes the base pairs of the final hits from them (hits of the wave kernel or
