@@ -978,6 +978,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if (!getenv("PRB_GAPPED_NO_RESUME")) {
     rs[0].cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
     rs[1].cap = (int32_t)std::min<int64_t>(nung / 32 + 1024, 1 << 20);
+    if (const char *e = getenv("PRB_GAPPED_RESUME_CAP")) // testing: pools that run out (those hits are redone instead)
+      rs[0].cap = rs[1].cap = std::max(1, atoi(e));
     if ((rc = w.resumeSlot.ensure((size_t)nung * 8)) || (rc = w.resumeCount.ensure(16)) ||
         (rc = w.resumePool.ensure((size_t)rs[0].cap * gapped_resume_bytes(0))) ||
         (rc = w.resumePool2.ensure((size_t)rs[1].cap * gapped_resume_bytes(1))))

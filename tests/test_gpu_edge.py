@@ -129,6 +129,9 @@ def test_results_do_not_depend_on_batch_composition(ctx, golden_dir, monkeypatch
         monkeypatch.setenv("PRB_GAPPED_NO_RESUME", "1")
         assert run(seqs) == full
         monkeypatch.delenv("PRB_GAPPED_NO_RESUME")
+        monkeypatch.setenv("PRB_GAPPED_RESUME_CAP", "5")  # the dump pools run out after five hits
+        assert run(seqs) == full
+        monkeypatch.delenv("PRB_GAPPED_RESUME_CAP")
         for q in (0, 17, 63):
             assert run([seqs[q]])[0] == full[q]
     finally:
