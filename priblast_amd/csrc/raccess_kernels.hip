@@ -24,6 +24,7 @@ namespace prb {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kRaAhead = 8; // interior-loop terms fetched ahead of the fold in k_inside / k_outside
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
 
@@ -229,18 +230,33 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
         double temp = type != 0 ? ra_hairpin_energy(lds, type, d, bi1, bj) : 0.0;
         // p <= j-5 and q >= p+5  <=>  u1 + u2 <= d - 5; the pass bound uses dtop
         const int m = imin(kMaxLoop, dtop - (kTurn + 2));
+        // (terms in blocks of kRaAhead: the band entries and sequence codes of a block are fetched
+        // together, so their HBM / L2 latency is paid once per block, not once per term; the fold
+        // itself stays in the reference's order)
         for (int u1 = 0; u1 <= m; u1++) {
-          for (int u2 = imin(kMaxLoop - u1, dtop - (kTurn + 2) - u1); u2 >= 0; u2--) {
-            if (u1 == 0 && u2 == 0) continue; // the (p,q) == (i,j) term is excluded (:207)
-            const int q = j - u2;
-            if (type != 0 && u1 + u2 <= d - (kTurn + 2)) {
-              const int p = i + u1;
-              const double st = EM(a_stem, p, q);
+          const int p = i + u1;
+          const int bp1 = type != 0 ? s[p + 1] : 0, bp0 = type != 0 ? s[p] : 0;
+          for (int u2hi = imin(kMaxLoop - u1, dtop - (kTurn + 2) - u1); u2hi >= 0; u2hi -= kRaAhead) {
+            double sts[kRaAhead];
+            int sq[kRaAhead], sq1[kRaAhead];
+#pragma unroll
+            for (int b = 0; b < kRaAhead; b++) {
+              const int u2 = u2hi - b;
+              // the (p,q) == (i,j) term is excluded (:207)
+              const bool ok = u2 >= 0 && !(u1 == 0 && u2 == 0) && type != 0 && u1 + u2 <= d - (kTurn + 2);
+              const int q = j - u2;
+              sts[b] = ok ? EM(a_stem, p, q) : kNegInf;
+              sq[b] = ok ? s[q] : 0;
+              sq1[b] = ok ? s[q + 1] : 0;
+            }
+#pragma unroll
+            for (int b = 0; b < kRaAhead; b++) {
+              const double st = sts[b];
               if (st != kNegInf) {
-                int type2 = ra_bp(lds, s[p + 1], s[q]);
+                int type2 = ra_bp(lds, bp1, sq[b]);
                 if (type2 != 0) {
                   type2 = ra_rtype(type2);
-                  const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2, bi1, bj, s[p], s[q + 1]);
+                  const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2hi - b, bi1, bj, bp0, sq1[b]);
                   temp = ra_lse(lds, temp, st + z);
                 }
               }
@@ -423,16 +439,29 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
       const int u1top = imin(m, q - dbot - 1); // i >= 1 for the smallest span of the pass
       for (int u1 = u1top; u1 >= 0; u1--) {
         const int u2top = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - dbot - u1);
-        for (int u2 = 0; u2 <= u2top; u2++) {
-          if (u1 == 0 && u2 == 0) continue; // (i,j) == (p,q) is excluded (:377)
-          const int j = q + u2;
-          if (t2raw != 0 && u1 <= p - 1 && d + u1 + u2 <= W + 1) {
-            const int i = p - u1;
-            const int type = ra_bp(lds, s[i], s[j + 1]);
-            if (type != 0) {
-              const double se = EM(b_stemend, i, j);
-              if (se != kNegInf) {
-                const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2, s[i + 1], s[j], bp0, bq1);
+        const bool row = t2raw != 0 && u1 <= p - 1;
+        const int i = p - u1;
+        const int bi0 = row ? s[i] : 0, bi1 = row ? s[i + 1] : 0;
+        for (int u2lo = 0; u2lo <= u2top; u2lo += kRaAhead) { // blocks of terms, see k_inside
+          double ses[kRaAhead];
+          int sj[kRaAhead], sj1[kRaAhead];
+#pragma unroll
+          for (int b = 0; b < kRaAhead; b++) {
+            const int u2 = u2lo + b;
+            // (i,j) == (p,q) is excluded (:377)
+            const bool ok = row && u2 <= u2top && !(u1 == 0 && u2 == 0) && d + u1 + u2 <= W + 1;
+            const int j = q + u2;
+            ses[b] = ok ? EM(b_stemend, i, j) : kNegInf;
+            sj[b] = ok ? s[j] : 0;
+            sj1[b] = ok ? s[j + 1] : 0;
+          }
+#pragma unroll
+          for (int b = 0; b < kRaAhead; b++) {
+            const double se = ses[b];
+            if (se != kNegInf) {
+              const int type = ra_bp(lds, bi0, sj1[b]);
+              if (type != 0) {
+                const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2lo + b, bi1, sj[b], bp0, bq1);
                 temp = ra_lse(lds, temp, se + z);
               }
             }
