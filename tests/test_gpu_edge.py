@@ -168,3 +168,33 @@ def test_final_gather_on_the_gpu_backend(tmp_path):
     r = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT, str(tmp_path / "rdv"), root], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "gather ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_query_longer_than_the_lds_staging(ctx, oracle, golden_dir):
+    """A 7.5 kb query does not fit the ungapped kernel's LDS staging (7168 slots) and sits in the
+    LOGSUM regime of Raccess (|log Z| > 690); a short query in the same batch takes the staged path.
+    Both against the oracle."""
+    from priblast_amd import capi
+    rng = random.Random(5)
+    long_q = "".join(rng.choice("ACGU") for _ in range(7500))
+    short_q = "".join(rng.choice("ACGU") for _ in range(150))
+    db = capi.Db(ctx, os.path.join(golden_dir, "c1db"))
+    odb = oracle.Db(os.path.join(golden_dir, "c1db"))
+    seqs = [short_q, long_q]
+    qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        hits, bp, counts = capi.search_page(ctx, qb, db, 0, capi.default_opts(output_style=1))
+        assert counts[2] > 0
+        for q, s in enumerate(seqs):
+            _, _, acc, cond = qb.get(q)
+            oacc, ocond = oracle.raccess(s, db.W, db.delta)
+            assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32)) and np.array_equal(cond.view(np.uint32), ocond.view(np.uint32))
+            _, _, gap = odb.stages(s, 0)
+            ref = [(h["db_sp"], h["q_sp"], h["db_len"], h["q_len"], h["db_id"], h["db_id_start"], h["e_acc"], h["e_hyb"],
+                    h["e_tot"], tuple(map(tuple, h["bp"].tolist()))) for h in gap]
+            assert sorted(per_query(hits, bp, q)) == sorted(ref), q
+    finally:
+        qb.close()
+        db.close()
+        odb.close()
