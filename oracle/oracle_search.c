@@ -355,12 +355,15 @@ void orc_extend_ungapped(const orc_db *db, int page, const orc_ris_opts *o, cons
     ungapped_one(&hits->h[x], pg, qenc, qacc, qcond, db->min_accessible_length, o->drop_wo_gap);
   sort_hits(hits);
   check_redundancy(hits, o->interaction_thr);
-  /* GetBasePair, rna_interaction_search.cpp:371-385 */
+  /* GetBasePair, rna_interaction_search.cpp:371-385.  The reference indexes BP_pair[5][5] with the
+   * raw codes minus 1, i.e. outside the table for soft-masked codes 6..9 (`db -r 1`): undefined
+   * behaviour, not restated - masked codes are mapped to their bases as in
+   * ungapped_extension.cpp:68-69. */
   for (size_t x = 0; x < hits->n; x++) {
     orc_hit *h = &hits->h[x];
     int len = US(h->q_len);
     for (int j = 0; j < len; j++)
-      if (pr->bp_pair[qenc[h->q_sp + j] - 1][pg->seqs[h->db_sp + j] - 1] != 0) add_bp(h, h->q_sp + j, h->db_sp + j);
+      if (pr->bp_pair[base_of(qenc[h->q_sp + j])][base_of(pg->seqs[h->db_sp + j])] != 0) add_bp(h, h->q_sp + j, h->db_sp + j);
   }
 }
 

@@ -880,8 +880,10 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       const uint8_t *qs = qb->enc.data() + qb->off[h.query];
       h.bp_offset = (int64_t)hs->bp.size() / 2;
       const int len = (int)(uint16_t)h.q_len;
+      // (soft-masked codes 6..9 mapped to their bases: the reference reads outside BP_pair for them)
+      auto code_base = [](unsigned c) { return c <= 5 ? (int)c - 1 : (int)c - 5; };
       for (int j = 0; j < len; j++)
-        if (ctx->params.bp_pair[qs[h.q_sp + j] - 1][pg.seqs[h.db_sp + j] - 1] != 0) {
+        if (ctx->params.bp_pair[code_base(qs[h.q_sp + j])][code_base(pg.seqs[h.db_sp + j])] != 0) {
           hs->bp.push_back(h.q_sp + j);
           hs->bp.push_back(h.db_sp + j);
           h.bp_count++;

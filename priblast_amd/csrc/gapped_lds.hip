@@ -781,7 +781,7 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
   c.ndiag = 0;
   if (kMode != 0) // GetBasePair, rna_interaction_search.cpp:371-385 (every lane counts; cheap)
     for (int t = 0; t < c.diag_len; t++)
-      c.ndiag += sc.bp_pair[(c.qs[c.diag_q + t] - 1) * 5 + (a.pg.seqs[c.diag_d + t] - 1)] != 0;
+      c.ndiag += diag_pairs(sc, c.qs[c.diag_q + t], a.pg.seqs[c.diag_d + t]);
   c.unsorted = kMode != 0 && a.first_flag && a.first_flag[x]; // hit 0 keeps raw pair order (:314-317)
   c.out0 = kMode == 2 ? a.bp_off[w] : 0;
   c.ovf = false;
@@ -891,7 +891,7 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
     int t = 0;
     const int64_t d0 = c.unsorted ? c.out0 : c.out0 + c.nleft;
     for (int u = 0; u < c.diag_len; u++)
-      if (sc.bp_pair[(c.qs[c.diag_q + u] - 1) * 5 + (ds[c.diag_d + u] - 1)] != 0) {
+      if (diag_pairs(sc, c.qs[c.diag_q + u], ds[c.diag_d + u])) {
         a.bp_out[2 * (d0 + t)] = c.diag_q + u;
         a.bp_out[2 * (d0 + t) + 1] = c.diag_d + u;
         t++;
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const ui
   const uint8_t *ds = pg.seqs + in.db_sp[x];
   const int len = US(in.q_len[x]);
   int c = 0;
-  for (int t = 0; t < len; t++) c += sc.bp_pair[(qs[t] - 1) * 5 + (ds[t] - 1)] != 0;
+  for (int t = 0; t < len; t++) c += diag_pairs(sc, qs[t], ds[t]);
   bp_count[w] = c + (ntrace[x] & 0xFFFF) + (int)((uint32_t)ntrace[x] >> 16);
 }
 
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_bp_expand(HitSoA in, int64_t n, const u
   int ndiag = 0;
   const int64_t d0 = unsorted ? out0 : out0 + nleft;
   for (int t = 0; t < len; t++)
-    if (sc.bp_pair[(qs[t] - 1) * 5 + (ds[t] - 1)] != 0) {
+    if (diag_pairs(sc, qs[t], ds[t])) {
       bp_out[2 * (d0 + ndiag)] = q_sp + t;
       bp_out[2 * (d0 + ndiag) + 1] = db_sp + t;
       ndiag++;

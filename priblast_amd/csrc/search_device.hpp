@@ -19,6 +19,13 @@ __device__ __forceinline__ int get_char(const uint8_t *s, int64_t i) {          
 __device__ __forceinline__ int bp_type(const SearchConst &sc, int a, int b) {
   return a == 0 ? 0 : (int)((sc.bp_rows >> (15 * (a - 1) + 3 * b)) & 7);
 }
+// GetBasePair's test (rna_interaction_search.cpp:371-385) for a position of the ungapped diagonal.
+// The reference indexes BP_pair[5][5] with the raw codes minus 1, which for soft-masked codes
+// (6..9, `db -r 1`) reads outside the table; here those are mapped to their bases like everywhere
+// else in the extension code (ungapped_extension.cpp:68-69), see DESIGN.md section 2.
+__device__ __forceinline__ bool diag_pairs(const SearchConst &sc, unsigned qc, unsigned dc) {
+  return sc.bp_pair[base_of(qc) * 5 + base_of(dc)] != 0;
+}
 __device__ __forceinline__ int rtype_of(int t) { return t == 0 ? 0 : ((t - 1) ^ 1) + 1; } // energy_par.hpp:26
 // z / 100.0 for an integer energy z (0.01 kcal/mol), correctly rounded without a division or
 // a table look-up: one Newton step on z * fl(1/100) with fused multiply-adds.  Bit-identical to the

@@ -113,3 +113,48 @@ def test_1kb_vs_200kb_against_reference_binary(ctx, tmp_path):
     a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
     assert len(b) > 3000
     assert a == b
+
+
+@pytest.mark.parametrize("repeat_flag", [1, 2])
+def test_repeat_flags_against_reference_binary(tmp_path, repeat_flag):
+    """Soft-masked (lower-case) stretches with `db -r 1` / `-r 2` (encoder.cpp:38-89): the database
+    files of the GPU build are byte-identical to the reference's, and `ris` prints the same lines."""
+    import random
+    from priblast_amd import capi
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.strict")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    rng = random.Random(100 + repeat_flag)
+
+    def seq(n):
+        s = [rng.choice("ACGU") for _ in range(n)]
+        for _ in range(n // 120):  # lower-case islands
+            a = rng.randrange(n - 30)
+            for t in range(a, a + rng.randrange(5, 30)):
+                s[t] = s[t].lower()
+        return "".join(s)
+
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    with open(dbfa, "w") as f:
+        for i in range(40):
+            f.write(f">db{i}\n{seq(400)}\n")
+    with open(qfa, "w") as f:
+        for i in range(6):
+            f.write(f">q{i}\n{seq(350)}\n")
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    for tool, out in ((ref, "rdb"), (capi.BIN_PATH, "gdb")):
+        subprocess.run([tool, "db", "-i", dbfa, "-o", str(tmp_path / out), "-r", str(repeat_flag), "-p", str(tmp_path)],
+                       check=True, env=env, cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    for ext in ("bas", "seq", "acc", "nam", "ind"):
+        with open(tmp_path / f"rdb.{ext}", "rb") as f, open(tmp_path / f"gdb.{ext}", "rb") as g:
+            assert f.read() == g.read(), ext
+    subprocess.run([ref, "ris", "-i", qfa, "-o", str(tmp_path / "ref.out"), "-d", str(tmp_path / "rdb"), "-p", str(tmp_path)],
+                   check=True, env=env, cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    subprocess.run([capi.BIN_PATH, "ris", "-i", qfa, "-o", str(tmp_path / "gpu.out"), "-d", str(tmp_path / "gdb")], check=True)
+
+    def body(p):
+        with open(p) as f:
+            return sorted(l.split(",", 1)[1] for l in f.read().splitlines()[3:])
+    a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
+    assert len(b) > 10
+    assert a == b
