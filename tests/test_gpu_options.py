@@ -158,3 +158,57 @@ def test_repeat_flags_against_reference_binary(tmp_path, repeat_flag):
     a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
     assert len(b) > 10
     assert a == b
+
+
+def test_nondefault_db_and_ris_options_through_the_command_lines(tmp_path):
+    """`db -w -d -s -c` and `ris -l -e -f -g -x -y -m -s 1` all at once, on FASTA files with CRLF line
+    ends, DNA letters (T), lower case and N: database files and result lines identical to the
+    reference binary's."""
+    import random
+    from priblast_amd import capi
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.strict")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    rng = random.Random(77)
+
+    def seq(n):
+        s = [rng.choice("ACGT") for _ in range(n)]
+        for t in range(0, n, 97):
+            s[t] = "N"
+        for t in range(40, min(n, 60)):
+            s[t] = s[t].lower()
+        return "".join(s)
+
+    def write(path, prefix, count, n):
+        with open(path, "w", newline="") as f:
+            for i in range(count):
+                s = seq(n + 13 * i)
+                f.write(f">{prefix}{i} some description\r\n")
+                for t in range(0, len(s), 70):
+                    f.write(s[t:t + 70] + "\r\n")
+
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    write(dbfa, "t", 30, 300)
+    write(qfa, "q", 5, 260)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    dbopts = ["-w", "50", "-d", "6", "-s", "6", "-c", "3000"]
+    for tool, out in ((ref, "rdb"), (capi.BIN_PATH, "gdb")):
+        subprocess.run([tool, "db", "-i", dbfa, "-o", str(tmp_path / out), "-p", str(tmp_path)] + dbopts,
+                       check=True, env=env, cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    for ext in ("bas", "seq", "acc", "nam", "ind"):
+        with open(tmp_path / f"rdb.{ext}", "rb") as f, open(tmp_path / f"gdb.{ext}", "rb") as g:
+            assert f.read() == g.read(), ext
+    risopts = ["-l", "12", "-e", "-5", "-f", "-3", "-g", "-6", "-x", "10", "-y", "4", "-m", "2", "-s", "1"]
+    subprocess.run([ref, "ris", "-i", qfa, "-o", str(tmp_path / "ref.out"), "-d", str(tmp_path / "rdb"), "-p", str(tmp_path)] + risopts,
+                   check=True, env=env, cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    subprocess.run([capi.BIN_PATH, "ris", "-i", qfa, "-o", str(tmp_path / "gpu.out"), "-d", str(tmp_path / "gdb")] + risopts,
+                   check=True)
+
+    def read(p):
+        with open(p) as f:
+            lines = f.read().splitlines()
+        return lines[1].split(",", 2)[2], sorted(l.split(",", 1)[1] for l in lines[3:])
+    (ha, a), (hb, b) = read(str(tmp_path / "gpu.out")), read(str(tmp_path / "ref.out"))
+    assert ha == hb  # the option echo of the header line (after input: and database:)
+    assert len(b) > 20
+    assert a == b
