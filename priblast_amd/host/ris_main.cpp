@@ -5,12 +5,17 @@
 // rna_interaction_search.cpp:322-369, 445-476).  `-a` and `-p` are accepted and ignored: the
 // MPI/OpenMP query schedulers are replaced by batched GPU stages; queries are dealt in
 // batches to the GPUs named by PRB_DEVICES (default: device 0).
+//
+// Two additions to the reference's surface (the output path): `ris -b` writes
+// the hits as binary records instead of text (no number formatting on the search path), and the
+// `txt` sub-command turns such a file into exactly the text `ris` would have written.
 #include <getopt.h>
 
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <map>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +55,7 @@ void usage() {
             "    -m INT    Minimum helix length in gapped extension [default:3]\n"
             "    -a STR    accepted for compatibility (block, area, dynamic); ignored\n"
             "    -p STR    accepted for compatibility; ignored\n"
+            "    -b        write binary hit records instead of text; `pRIblast-hip txt -i FILE -o TEXT` converts\n"
             "\n"
             "  Environment: PRB_DEVICES=0,1,..  GPUs to use;  PRB_BATCH=N  queries per batch [default 2048]");
 }
@@ -57,6 +63,7 @@ void usage() {
 struct Args {
   std::string in, out, db;
   prb_ris_opts o;
+  bool binary = false;
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -70,7 +77,28 @@ struct Worker {
   prb_db *db = nullptr;
 };
 
-// The hit sets of one batch (one per database page), waiting to be turned into text.
+// What the output needs to know about the sequences of one database page.
+struct SeqTable {
+  std::vector<std::string> names;
+  std::vector<int32_t> len, len_unmasked, start_pos;
+};
+
+// The hits of one batch against one page, and a batch: plain arrays, wherever they live (hit sets
+// of the library, or a binary hit file read back).
+struct PageHits {
+  const prb_hit *h = nullptr;
+  int64_t n = 0;
+  const int32_t *bp = nullptr;
+  int64_t nbp = 0; // pairs
+};
+struct BatchView {
+  size_t nq = 0;
+  const std::string *names = nullptr; // [nq]
+  const int32_t *qlen_unmasked = nullptr;
+  std::vector<PageHits> pages;
+};
+
+// The hit sets of one batch (one per database page), waiting to be written.
 struct BatchJob {
   size_t index = 0, b0 = 0, nq = 0;
   Worker *w = nullptr;
@@ -89,12 +117,12 @@ int format_threads() {
 // grouped by query in ascending order (sub-batches of ascending queries, each sorted by
 // (query, db position)), so a query's hits are one contiguous range per page; queries are
 // formatted in parallel.
-int64_t format_batch(const BatchJob &job, const Args &a, const std::vector<std::string> &names, int64_t id0, std::FILE *out) {
-  const size_t nq = job.nq, np = job.pages.size();
+int64_t format_batch(const BatchView &v, const std::vector<SeqTable> &tabs, int output_style, int64_t id0, std::FILE *out) {
+  const size_t nq = v.nq, np = v.pages.size();
   std::vector<std::vector<int64_t>> first(np, std::vector<int64_t>(nq + 1, 0)); // first[p][q] = first hit of query q
   for (size_t p = 0; p < np; p++) {
-    const int64_t n = prb_hitset_size(job.pages[p]);
-    const prb_hit *h = prb_hitset_hits(job.pages[p]);
+    const int64_t n = v.pages[p].n;
+    const prb_hit *h = v.pages[p].h;
     size_t q = 0;
     for (int64_t i = 0; i < n; i++)
       while (q < nq && (int64_t)q <= h[i].query) first[p][q++] = i;
@@ -114,24 +142,23 @@ int64_t format_batch(const BatchJob &job, const Args &a, const std::vector<std::
     char buf[512];
     int64_t id = base[q];
     for (size_t p = 0; p < np; p++) {
-      const prb_hit *h = prb_hitset_hits(job.pages[p]);
-      int64_t nbp = 0;
-      const int32_t *bp = prb_hitset_basepairs(job.pages[p], &nbp);
+      const prb_hit *h = v.pages[p].h;
+      const int32_t *bp = v.pages[p].bp;
+      const SeqTable &tab = tabs[p];
       for (int64_t i = first[p][q]; i < first[p][q + 1]; i++) {
         const prb_hit &x = h[i];
-        int32_t len = 0, len_rep = 0, sp = 0;
-        prb_db_seq_lengths(job.w->db, (int32_t)p, x.db_id, &len, &len_rep, &sp);
+        const int32_t len = tab.len[x.db_id], sp = tab.start_pos[x.db_id];
         std::snprintf(buf, sizeof buf, "%lld,", (long long)id++);
         s += buf;
-        s += names[job.b0 + q];
-        std::snprintf(buf, sizeof buf, ",%d,", job.qlen_unmasked[q]);
+        s += v.names[q];
+        std::snprintf(buf, sizeof buf, ",%d,", v.qlen_unmasked[q]);
         s += buf;
-        s += prb_db_seq_name(job.w->db, (int32_t)p, x.db_id);
-        std::snprintf(buf, sizeof buf, ",%d,%g,%g,%g,", len_rep, x.e_acc, x.e_hyb, x.e_tot);
+        s += tab.names[x.db_id];
+        std::snprintf(buf, sizeof buf, ",%d,%g,%g,%g,", tab.len_unmasked[x.db_id], x.e_acc, x.e_hyb, x.e_tot);
         s += buf;
         const int32_t *pp = bp + 2 * x.bp_offset;
         auto fwd = [&](int32_t dbpos) { return (len - 1) - (dbpos - sp); }; // reversed text -> forward coordinate
-        if (a.o.output_style == 1) {
+        if (output_style == 1) {
           for (int32_t j = 0; j < x.bp_count; j++) {
             std::snprintf(buf, sizeof buf, "(%d:%d) ", pp[2 * j], fwd(pp[2 * j + 1]));
             s += buf;
@@ -148,6 +175,155 @@ int64_t format_batch(const BatchJob &job, const Args &a, const std::vector<std::
   for (auto &s : text)
     if (!s.empty() && std::fwrite(s.data(), 1, s.size(), out) != s.size()) die("Error: can't write the output file");
   return base[nq];
+}
+
+// ---- binary hit file (little-endian, the layouts of include/priblast_hip.h) ----------------------
+//   "PRBHITS\1" | i32 output_style | i32 npages | str header (the three text lines)
+//   per page: i32 nseq, then per sequence i32 length, i32 length_unmasked, i32 start_pos, str name
+//   blocks:   i64 'B' | i64 nq | per query: str name, i32 length_unmasked
+//             | per page: i64 nhits, i64 npairs, prb_hit[nhits], int32[2 * npairs]
+//   trailer:  i64 'E' | i64 total hits
+//   str = i32 length + bytes.  prb_hit.bp_offset indexes the pair array of its own block and page.
+constexpr char kMagic[8] = {'P', 'R', 'B', 'H', 'I', 'T', 'S', 1};
+constexpr int64_t kBlock = 'B', kEnd = 'E';
+
+void put(std::FILE *f, const void *p, size_t n) {
+  if (n && std::fwrite(p, 1, n, f) != n) die("Error: can't write the output file");
+}
+template <class T> void put(std::FILE *f, T v) { put(f, &v, sizeof v); }
+void put_str(std::FILE *f, const std::string &s) {
+  put<int32_t>(f, (int32_t)s.size());
+  put(f, s.data(), s.size());
+}
+void get(std::FILE *f, void *p, size_t n) {
+  if (n && std::fread(p, 1, n, f) != n) die("Error: truncated binary hit file");
+}
+template <class T> T get(std::FILE *f) {
+  T v;
+  get(f, &v, sizeof v);
+  return v;
+}
+std::string get_str(std::FILE *f) {
+  const int32_t n = get<int32_t>(f);
+  if (n < 0 || n > (1 << 28)) die("Error: corrupt binary hit file");
+  std::string s((size_t)n, '\0');
+  get(f, s.data(), s.size());
+  return s;
+}
+
+void write_binary_head(std::FILE *f, int output_style, const std::string &header, const std::vector<SeqTable> &tabs) {
+  put(f, kMagic, sizeof kMagic);
+  put<int32_t>(f, output_style);
+  put<int32_t>(f, (int32_t)tabs.size());
+  put_str(f, header);
+  for (const SeqTable &t : tabs) {
+    put<int32_t>(f, (int32_t)t.names.size());
+    for (size_t i = 0; i < t.names.size(); i++) {
+      put<int32_t>(f, t.len[i]);
+      put<int32_t>(f, t.len_unmasked[i]);
+      put<int32_t>(f, t.start_pos[i]);
+      put_str(f, t.names[i]);
+    }
+  }
+}
+
+int64_t write_binary_batch(const BatchView &v, std::FILE *f) {
+  put<int64_t>(f, kBlock);
+  put<int64_t>(f, (int64_t)v.nq);
+  for (size_t q = 0; q < v.nq; q++) {
+    put_str(f, v.names[q]);
+    put<int32_t>(f, v.qlen_unmasked[q]);
+  }
+  int64_t total = 0;
+  for (const PageHits &p : v.pages) {
+    put<int64_t>(f, p.n);
+    put<int64_t>(f, p.nbp);
+    put(f, p.h, (size_t)p.n * sizeof(prb_hit));
+    put(f, p.bp, (size_t)p.nbp * 2 * sizeof(int32_t));
+    total += p.n;
+  }
+  return total;
+}
+
+// `txt` sub-command: binary hit file -> the text `ris` writes.
+int txt_main(int argc, char **argv) {
+  std::string in, out;
+  int c;
+  while ((c = getopt(argc, argv, "i:o:")) != -1) {
+    switch (c) {
+    case 'i': in = optarg; break;
+    case 'o': out = optarg; break;
+    default: die("Error: invalid argument");
+    }
+  }
+  std::FILE *f = std::fopen(in.c_str(), "rb");
+  if (!f) die("Error: can't open input_file: " + in);
+  char magic[8];
+  get(f, magic, sizeof magic);
+  if (std::memcmp(magic, kMagic, sizeof kMagic)) die("Error: " + in + " is not a binary hit file");
+  const int output_style = get<int32_t>(f);
+  const int np = get<int32_t>(f);
+  if (np < 0 || np > (1 << 24)) die("Error: corrupt binary hit file");
+  const std::string header = get_str(f);
+  std::vector<SeqTable> tabs((size_t)np);
+  for (SeqTable &t : tabs) {
+    const int32_t nseq = get<int32_t>(f);
+    if (nseq < 0) die("Error: corrupt binary hit file");
+    for (int32_t i = 0; i < nseq; i++) {
+      t.len.push_back(get<int32_t>(f));
+      t.len_unmasked.push_back(get<int32_t>(f));
+      t.start_pos.push_back(get<int32_t>(f));
+      t.names.push_back(get_str(f));
+    }
+  }
+  std::FILE *o = std::fopen(out.c_str(), "w");
+  if (!o) die("Error: can't open output_file: " + out);
+  put(o, header.data(), header.size());
+  int64_t id = 0;
+  for (;;) {
+    const int64_t tag = get<int64_t>(f);
+    if (tag == kEnd) {
+      if (get<int64_t>(f) != id) die("Error: corrupt binary hit file (hit count)");
+      break;
+    }
+    if (tag != kBlock) die("Error: corrupt binary hit file");
+    const int64_t nq = get<int64_t>(f);
+    if (nq < 0 || nq > (1 << 28)) die("Error: corrupt binary hit file");
+    std::vector<std::string> names((size_t)nq);
+    std::vector<int32_t> qlen((size_t)nq);
+    for (int64_t q = 0; q < nq; q++) {
+      names[q] = get_str(f);
+      qlen[q] = get<int32_t>(f);
+    }
+    std::vector<std::vector<prb_hit>> hits((size_t)np);
+    std::vector<std::vector<int32_t>> pairs((size_t)np);
+    BatchView v;
+    v.nq = (size_t)nq;
+    v.names = names.data();
+    v.qlen_unmasked = qlen.data();
+    for (int p = 0; p < np; p++) {
+      const int64_t n = get<int64_t>(f), nbp = get<int64_t>(f);
+      if (n < 0 || nbp < 0) die("Error: corrupt binary hit file");
+      hits[p].resize((size_t)n);
+      pairs[p].resize((size_t)nbp * 2);
+      get(f, hits[p].data(), (size_t)n * sizeof(prb_hit));
+      get(f, pairs[p].data(), (size_t)nbp * 2 * sizeof(int32_t));
+      for (const prb_hit &x : hits[p])
+        if (x.query < 0 || x.query >= nq || x.db_id < 0 || (size_t)x.db_id >= tabs[p].names.size() || x.bp_count < 0 ||
+            x.bp_offset < 0 || x.bp_offset + x.bp_count > nbp)
+          die("Error: corrupt binary hit file (record)");
+      PageHits ph;
+      ph.h = hits[p].data();
+      ph.n = n;
+      ph.bp = pairs[p].data();
+      ph.nbp = nbp;
+      v.pages.push_back(ph);
+    }
+    id = format_batch(v, tabs, output_style, id, o);
+  }
+  std::fclose(f);
+  if (std::fclose(o)) die("Error: can't write the output file");
+  return 0;
 }
 
 // One batch through the GPU stages; the hit sets go to the writer.
@@ -179,7 +355,7 @@ int ris_main(int argc, char **argv) {
   Args a;
   prb_ris_opts_default(&a.o);
   int c;
-  while ((c = getopt(argc, argv, "i:o:d:l:e:y:x:f:g:s:m:p:a:")) != -1) {
+  while ((c = getopt(argc, argv, "i:o:d:l:e:y:x:f:g:s:m:p:a:b")) != -1) {
     switch (c) {
     case 'i': a.in = optarg; break;
     case 'o': a.out = optarg; break;
@@ -193,6 +369,7 @@ int ris_main(int argc, char **argv) {
     case 'y': a.o.drop_out_wo_gap = std::atoi(optarg); break;
     case 'm': a.o.min_helix_length = std::atoi(optarg); break;
     case 'p': break;
+    case 'b': a.binary = true; break;
     case 'a':
       if (std::strcmp(optarg, "block") && std::strcmp(optarg, "area") && std::strcmp(optarg, "dynamic"))
         die("Error: parallel algorithm not supported.");
@@ -222,18 +399,41 @@ int ris_main(int argc, char **argv) {
   }
   prb_db_info(workers[0].db, &hash_size, &repeat_flag, &W, &delta, &npages);
 
-  std::FILE *out = std::fopen(a.out.c_str(), "w");
+  std::vector<SeqTable> tabs((size_t)npages);
+  for (int p = 0; p < npages; p++) {
+    int32_t nseq = 0;
+    int64_t nchars = 0;
+    prb_db_page_info(workers[0].db, p, &nseq, &nchars);
+    SeqTable &t = tabs[p];
+    t.names.resize(nseq);
+    t.len.resize(nseq);
+    t.len_unmasked.resize(nseq);
+    t.start_pos.resize(nseq);
+    for (int32_t i = 0; i < nseq; i++) {
+      t.names[i] = prb_db_seq_name(workers[0].db, p, i);
+      prb_db_seq_lengths(workers[0].db, p, i, &t.len[i], &t.len_unmasked[i], &t.start_pos[i]);
+    }
+  }
+
+  std::FILE *out = std::fopen(a.out.c_str(), a.binary ? "wb" : "w");
   if (!out) die("Error: can't open output_file: " + a.out);
   // MergeOutput header, rna_interaction_search.cpp:445-463
-  std::fprintf(out, "RIblast ris result\n");
-  std::fprintf(out,
-               "input:%s,database:%s,RepeatFlag:%d,MaximalSpan:%d,MinAccessibleLength:%d,MaxSeedLength:%d,"
-               "InteractionEnergyThreshold:%g,HybridEnergyThreshold:%g,FinalThreshold:%g,DropOutLengthWoGap:%d,"
-               "DropOutLengthWGap:%d\n",
-               a.in.c_str(), a.db.c_str(), repeat_flag, W, delta, a.o.max_seed_length, a.o.interaction_threshold,
-               a.o.hybrid_threshold, a.o.final_threshold, a.o.drop_out_wo_gap, a.o.drop_out_w_gap);
-  std::fprintf(out, "Id,Query name, Query Length, Target name, Target Length, Accessibility Energy, Hybridization Energy, "
-                    "Interaction Energy, BasePair\n");
+  std::string header = "RIblast ris result\n";
+  {
+    char buf[256];
+    header += "input:" + a.in + ",database:" + a.db;
+    std::snprintf(buf, sizeof buf,
+                  ",RepeatFlag:%d,MaximalSpan:%d,MinAccessibleLength:%d,MaxSeedLength:%d,"
+                  "InteractionEnergyThreshold:%g,HybridEnergyThreshold:%g,FinalThreshold:%g,DropOutLengthWoGap:%d,"
+                  "DropOutLengthWGap:%d\n",
+                  repeat_flag, W, delta, a.o.max_seed_length, a.o.interaction_threshold, a.o.hybrid_threshold,
+                  a.o.final_threshold, a.o.drop_out_wo_gap, a.o.drop_out_w_gap);
+    header += buf;
+  }
+  header += "Id,Query name, Query Length, Target name, Target Length, Accessibility Energy, Hybridization Energy, "
+            "Interaction Energy, BasePair\n";
+  if (a.binary) write_binary_head(out, a.o.output_style, header, tabs);
+  else put(out, header.data(), header.size());
 
   const char *benv = std::getenv("PRB_BATCH");
   const size_t batch = std::max(1, benv ? std::atoi(benv) : 2048);
@@ -246,6 +446,7 @@ int ris_main(int argc, char **argv) {
   std::condition_variable cv;
   std::map<size_t, BatchJob> done;
   size_t written = 0;
+  int64_t total_hits = 0;
   std::thread writer([&] {
     int64_t id = 0;
     for (size_t b = 0; b < nb; b++) {
@@ -256,7 +457,19 @@ int ris_main(int argc, char **argv) {
         job = std::move(done[b]);
         done.erase(b);
       }
-      id = format_batch(job, a, names, id, out);
+      BatchView v;
+      v.nq = job.nq;
+      v.names = names.data() + job.b0;
+      v.qlen_unmasked = job.qlen_unmasked.data();
+      for (prb_hitset *hs : job.pages) {
+        PageHits ph;
+        ph.n = prb_hitset_size(hs);
+        ph.h = prb_hitset_hits(hs);
+        ph.bp = prb_hitset_basepairs(hs, &ph.nbp);
+        v.pages.push_back(ph);
+      }
+      if (a.binary) id += write_binary_batch(v, out);
+      else id = format_batch(v, tabs, a.o.output_style, id, out);
       for (prb_hitset *hs : job.pages) prb_hitset_free(hs);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -264,6 +477,7 @@ int ris_main(int argc, char **argv) {
       }
       cv.notify_all();
     }
+    total_hits = id;
   });
   std::vector<std::thread> threads;
   for (auto &w : workers)
@@ -287,7 +501,11 @@ int ris_main(int argc, char **argv) {
     });
   for (auto &t : threads) t.join();
   writer.join();
-  std::fclose(out);
+  if (a.binary) {
+    put<int64_t>(out, kEnd);
+    put<int64_t>(out, total_hits);
+  }
+  if (std::fclose(out)) die("Error: can't write the output file");
   for (auto &w : workers) {
     prb_db_close(w.db);
     prb_ctx_destroy(w.ctx);
@@ -346,6 +564,7 @@ int main(int argc, char **argv) {
   }
   if (std::strcmp(argv[1], "ris") == 0) return ris_main(argc - 1, argv + 1);
   if (std::strcmp(argv[1], "db") == 0) return db_main(argc - 1, argv + 1);
-  std::puts("usage: pRIblast-hip [-h] {db | ris} options");
+  if (std::strcmp(argv[1], "txt") == 0) return txt_main(argc - 1, argv + 1);
+  std::puts("usage: pRIblast-hip [-h] {db | ris | txt} options");
   return 0;
 }

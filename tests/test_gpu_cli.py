@@ -51,3 +51,19 @@ def test_cli_errors(tmp_path):
     assert r.returncode == 1 and "can't open" in r.stderr
     r = subprocess.run([capi.BIN_PATH], capture_output=True, text=True)
     assert r.returncode == 0 and "ris" in r.stdout
+
+
+@pytest.mark.parametrize("style", [0, 1])
+def test_binary_output_converts_to_the_same_text(golden_dir, tmp_path, style):
+    """`ris -b` + `txt` = `ris`, byte for byte (header, Ids, order), on the 3-page database with
+    several batches."""
+    from priblast_amd import capi
+    env = dict(os.environ, PRB_BATCH="3")
+    common = ["-i", os.path.join(GOLDEN, "mix_q.fa"), "-d", os.path.join(golden_dir, "mixdb"), "-s", str(style)]
+    txt, prb, back = str(tmp_path / "a.txt"), str(tmp_path / "a.prb"), str(tmp_path / "b.txt")
+    subprocess.run([capi.BIN_PATH, "ris", "-o", txt] + common, check=True, env=env)
+    subprocess.run([capi.BIN_PATH, "ris", "-b", "-o", prb] + common, check=True, env=env)
+    subprocess.run([capi.BIN_PATH, "txt", "-i", prb, "-o", back], check=True)
+    with open(txt, "rb") as f, open(back, "rb") as g:
+        a, b = f.read(), g.read()
+    assert a.count(b"\n") > 10 and a == b

@@ -92,3 +92,92 @@ def test_division_free_div100_is_exact(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True)
     assert out.stdout.strip() == "0"
+
+
+def _write_hit_file(path, style, header, tabs, blocks, trailer=True):
+    """The binary hit file of `pRIblast-hip ris -b` (layout: priblast_amd/host/ris_main.cpp)."""
+    import struct
+    def s(x):
+        b = x.encode()
+        return struct.pack("<i", len(b)) + b
+    total = 0
+    with open(path, "wb") as f:
+        f.write(b"PRBHITS\x01" + struct.pack("<ii", style, len(tabs)) + s(header))
+        for t in tabs:
+            f.write(struct.pack("<i", len(t)))
+            for name, ln, lu, sp in t:
+                f.write(struct.pack("<iii", ln, lu, sp) + s(name))
+        for qnames, qlens, pages in blocks:
+            f.write(struct.pack("<qq", ord("B"), len(qnames)))
+            for n, l in zip(qnames, qlens):
+                f.write(s(n) + struct.pack("<i", l))
+            for hits, bp in pages:
+                f.write(struct.pack("<qq", len(hits), len(bp)) + hits.tobytes() + bp.astype("<i4").tobytes())
+                total += len(hits)
+        if trailer:
+            f.write(struct.pack("<qq", ord("E"), total))
+
+
+def test_binary_hit_file_to_text(tmp_path):
+    """`pRIblast-hip txt`: binary hit records -> the lines SaveMyResults writes
+    (rna_interaction_search.cpp:322-369): running Id over blocks, queries in order with their pages
+    in order, %g energies, forward db coordinates, both output styles; damaged files are refused."""
+    import subprocess
+    from priblast_amd import capi
+    if not os.path.exists(capi.BIN_PATH):
+        pytest.skip("command line not built")
+    rng = np.random.default_rng(3)
+    tabs = [[("t0 first", 50, 50, 0), ("t1", 40, 38, 51)], [("u0", 70, 70, 0)]]
+    header = "RIblast ris result\ninput:a,database:b\nId,cols\n"
+
+    def page(nq, tab, npairs):
+        n = int(rng.integers(0, 7))
+        hits = np.zeros(n, capi.HIT_DTYPE)
+        hits["query"] = np.sort(rng.integers(0, nq, n))
+        hits["db_id"] = rng.integers(0, len(tab), n)
+        for k in ("e_acc", "e_hyb", "e_tot"):
+            hits[k] = rng.normal(-9, 5, n) * rng.choice([1.0, 1e-3, 1e3], n)
+        hits["bp_count"] = npairs if npairs else rng.integers(1, 6, n)
+        hits["bp_offset"] = np.concatenate([[0], np.cumsum(hits["bp_count"])[:-1]]) if n else 0
+        bp = rng.integers(0, 40, (int(hits["bp_count"].sum()), 2)).astype(np.int32)
+        for h in hits:  # db positions inside the sequence's slice of the reversed page text
+            ln, sp = tab[h["db_id"]][1], tab[h["db_id"]][3]
+            bp[h["bp_offset"]:h["bp_offset"] + h["bp_count"], 1] = sp + rng.integers(0, ln, h["bp_count"])
+        return hits, bp
+
+    for style in (0, 1):
+        blocks = []
+        for nq in (3, 1, 4):
+            qn = [f"q{len(blocks)}_{i} desc" for i in range(nq)]
+            blocks.append((qn, list(range(100, 100 + nq)), [page(nq, t, 2 if style == 0 else 0) for t in tabs]))
+        blocks.insert(1, ([], [], [(np.zeros(0, capi.HIT_DTYPE), np.zeros((0, 2), np.int32)) for _ in tabs]))
+        expect, gid = [header], 0
+        for qn, ql, pages in blocks:
+            for q in range(len(qn)):
+                for t, (hits, bp) in zip(tabs, pages):
+                    for h in hits[hits["query"] == q]:
+                        name, ln, lu, sp = t[h["db_id"]]
+                        pp = bp[h["bp_offset"]:h["bp_offset"] + h["bp_count"]]
+                        fwd = lambda x: (ln - 1) - (int(x) - sp)
+                        if style == 1:
+                            tail = "".join(f"({a}:{fwd(b)}) " for a, b in pp)
+                        else:
+                            tail = f"({pp[0][0]}-{pp[-1][0]}:{fwd(pp[0][1])}-{fwd(pp[-1][1])}) "
+                        expect.append("%d,%s,%d,%s,%d,%g,%g,%g,%s\n" % (gid, qn[q], ql[q], name, lu, h["e_acc"], h["e_hyb"], h["e_tot"], tail))
+                        gid += 1
+        assert gid > 5
+        src, dst = str(tmp_path / f"h{style}.prb"), str(tmp_path / f"h{style}.txt")
+        _write_hit_file(src, style, header, tabs, blocks)
+        subprocess.run([capi.BIN_PATH, "txt", "-i", src, "-o", dst], check=True)
+        with open(dst) as f:
+            assert f.read() == "".join(expect)
+        # no trailer (an interrupted run) and a record pointing outside its tables are errors, not text
+        _write_hit_file(src, style, header, tabs, blocks, trailer=False)
+        r = subprocess.run([capi.BIN_PATH, "txt", "-i", src, "-o", dst], capture_output=True, text=True)
+        assert r.returncode == 1 and "truncated" in r.stderr
+        bad = [(qn, ql, [(h.copy(), b) for h, b in pages]) for qn, ql, pages in blocks]
+        victim = next(h for _, _, pages in bad for h, _ in pages if len(h))
+        victim["db_id"][0] = 99
+        _write_hit_file(src, style, header, tabs, bad)
+        r = subprocess.run([capi.BIN_PATH, "txt", "-i", src, "-o", dst], capture_output=True, text=True)
+        assert r.returncode == 1 and "corrupt" in r.stderr
