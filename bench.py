@@ -196,6 +196,9 @@ def main():
     db = capi.Db(ctx, dbprefix)
     opts = capi.default_opts()
 
+    shape = {(5000, 1000): "BASELINE configs[1] shape", (50000, 2000): "BASELINE configs[2] database, a sample of its queries",
+             (32, 200): "BASELINE configs[0] shape"}.get((a.db_seqs, a.length), "not a BASELINE config")
+
     def step(k):
         """one batch of a.queries queries of this rank through the whole hot path"""
         lo, hi = pdist.batch_slice(k, rank, world, a.queries)
@@ -269,7 +272,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"ris: {a.queries} x {a.length} nt synthetic queries per GPU per step vs {a.db_seqs}-seq x "
-                                   f"{a.length} nt database (BASELINE configs[1] shape), full pipeline on the GPU",
+                                   f"{a.length} nt database ({shape}), full pipeline on the GPU",
                        "queries_per_step_per_gpu": a.queries, "db_seqs": a.db_seqs, "length": a.length,
                        "hits_per_step": {"seed": allc[0] // a.steps, "ungapped": allc[1] // a.steps, "final": allc[2] // a.steps},
                        "parallelism": f"queries sharded over {world} GPU(s), final hits gathered over RCCL"},

@@ -212,3 +212,44 @@ def test_nondefault_db_and_ris_options_through_the_command_lines(tmp_path):
     assert ha == hb  # the option echo of the header line (after input: and database:)
     assert len(b) > 20
     assert a == b
+
+
+def test_mixed_lengths_against_reference_binary(tmp_path):
+    """BASELINE configs[4] in miniature (synthetic): sequences from 150 nt to 12 kb on both sides, some
+    GC-rich, i.e. every Raccess regime (exact linear, float-overflow, LOGSUM) and every gapped kernel in
+    one run.  Database files and result lines against the reference binary."""
+    import random
+    from priblast_amd import capi
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.strict")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    rng = random.Random(4)
+
+    def seq(n, gc=0.5):
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AU") for _ in range(n))
+
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    with open(dbfa, "w") as f:
+        for i in range(36):
+            n = [150, 12000, 330, 5000][i] if i < 4 else int(rng.uniform(150, 6000))
+            f.write(f">t{i} len={n}\n{seq(n, 0.7 if i % 9 == 5 else 0.5)}\n")
+    with open(qfa, "w") as f:
+        for i, (n, gc) in enumerate([(180, 0.5), (900, 0.5), (3100, 0.5), (9000, 0.5), (2000, 0.7)]):
+            f.write(f">q{i}\n{seq(n, gc)}\n")
+    env = dict(os.environ, OMP_NUM_THREADS="16")
+    for tool, out in ((ref, "rdb"), (capi.BIN_PATH, "gdb")):
+        subprocess.run([tool, "db", "-i", dbfa, "-o", str(tmp_path / out), "-c", "40000", "-p", str(tmp_path)],
+                       check=True, env=env, cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    for ext in ("bas", "seq", "acc", "nam", "ind"):
+        with open(tmp_path / f"rdb.{ext}", "rb") as f, open(tmp_path / f"gdb.{ext}", "rb") as g:
+            assert f.read() == g.read(), ext
+    subprocess.run([ref, "ris", "-i", qfa, "-o", str(tmp_path / "ref.out"), "-d", str(tmp_path / "rdb"), "-p", str(tmp_path), "-s", "1"],
+                   check=True, env=env, cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    subprocess.run([capi.BIN_PATH, "ris", "-i", qfa, "-o", str(tmp_path / "gpu.out"), "-d", str(tmp_path / "gdb"), "-s", "1"], check=True)
+
+    def body(p):
+        with open(p) as f:
+            return sorted(l.split(",", 1)[1] for l in f.read().splitlines()[3:])
+    a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
+    assert len(b) > 1000
+    assert a == b
