@@ -79,7 +79,7 @@ void prb_ctx_destroy(prb_ctx *ctx);
 int prb_ctx_synchronize(prb_ctx *ctx);
 /* device time (ms, HIP events on the library's stream) of the named stage since the last
  * reset, and launch counts: "raccess", "seed", "ungapped", "sort", "filter", "gapped" (LDS tier 0),
- * "gapped_t1", "gapped_t2", "gapped_slow" (HBM-scratch kernel), "traceback", "traceback_slow";
+ * "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow" (HBM-scratch kernel), "traceback", "traceback_slow";
  * host wall-clock pseudo stages: "host_dfs" (background seed DFS), "host_dfs_wait",
  * "host_search_range", "host_cands", "host_drain_tail". */
 int prb_ctx_stage_ms(prb_ctx *ctx, const char *stage, double *ms, int64_t *launches);

@@ -69,12 +69,12 @@ struct PinnedBuf {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumeCount;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumeCount})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount})
       b->release();
     pinned.release();
     cand_pinned.release();
@@ -779,7 +779,6 @@ static int download_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, 
   return PRB_OK;
 }
 
-// all stages for the queries [q0, q1) of the batch against one page
 // One sub-batch of queries through the GPU stages.  cd (pinned host memory) = its seed candidates in
 // query order, row0 filled in; nrows = their database SA entries in total.
 static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, const prb_ris_opts &opts, int last_stage,
@@ -794,7 +793,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // ---- seeds: one row per (candidate, db SA entry) ----
   if (ncand64 == 0) return PRB_OK;
   if (ncand64 > INT32_MAX) {
-    set_error("too many seed candidates in one sub-batch: lower PRB_SEARCH_PAIRS");
+    set_error("too many seed candidates in one sub-batch: lower PRB_SEARCH_PAIRS, or build the database in smaller pages (db -c)");
     return PRB_ERR_NOMEM;
   }
   const int32_t ncand = (int32_t)ncand64;
@@ -824,7 +823,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   hs->counts[0] += nseed;
   if (nseed == 0) return ctx->time_end("seed", 2);
   if (nseed > (int64_t)UINT32_MAX - 16) {
-    set_error("too many seed hits in one sub-batch: lower PRB_SEARCH_PAIRS");
+    set_error("too many seed hits in one sub-batch: lower PRB_SEARCH_PAIRS, or, if a single query exceeds 4e9 seed hits against this page, build the database in smaller pages (db -c)");
     return PRB_ERR_NOMEM;
   }
   if ((rc = w.hitsA.ensure(hits_bytes(nseed)))) return rc;
@@ -900,14 +899,15 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       (rc = w.listA.ensure((size_t)nung * 4)) || (rc = w.listB.ensure((size_t)nung * 4)) || (rc = w.count.ensure(16)) ||
       (rc = w.trace.ensure((size_t)nung * 2 * kTraceCap * sizeof(uint16_t))))
     return rc;
-  // The cascade of kernels a hit goes through until one has the capacity for it: LDS tier 0
-  // (8 lanes per hit), LDS tier 1 (16 lanes), LDS tier 2 (a wavefront per hit), then the
-  // wave-per-hit kernel with HBM scratch of any size.
+  // The cascade of kernels a hit goes through until one has the capacity for it: LDS tiers 0 and 1
+  // (8 lanes per hit), tier 2 (16 lanes), tier 3 (a wavefront per hit), then the wave-per-hit kernel
+  // with HBM scratch of any size.
   // The environment switches exist for the tests: they force the rarely taken kernels.
-  std::vector<int> cascade{0, 1, 2, 3};
-  if (getenv("PRB_FORCE_WAVE_GAPPED")) cascade = {3};
-  else if (getenv("PRB_GAPPED_SKIP_TIER1")) cascade = {2, 3};
-  else if (getenv("PRB_GAPPED_SKIP_TIER0")) cascade = {1, 3};
+  std::vector<int> cascade{0, 1, 2, 3, kWaveTier};
+  if (getenv("PRB_FORCE_WAVE_GAPPED")) cascade = {kWaveTier};
+  else if (getenv("PRB_GAPPED_SKIP_TIER1")) cascade = {3, kWaveTier};
+  else if (getenv("PRB_GAPPED_SKIP_TIER0")) cascade = {2, kWaveTier};
+  else if (getenv("PRB_GAPPED_SKIP_SMALL")) cascade = {1, 2, 3, kWaveTier};
   auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
     gs.cap_diag = cap_diag;
     gs.cap_rec = cap_rec;
@@ -973,29 +973,28 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     return PRB_OK;
   };
   PRB_HIP(hipMemsetAsync(w.tierOf.p, 0, (size_t)nung, ctx->stream)); // no hit carries a resume mark yet
-  // state dumps for the hits that outgrow tier 0 (~4 %: room for one hit in eight, at most 2 M) and
-  // tier 1 (~0.7 %: one in 32, at most 1 M)
+  // state dumps for the hits that outgrow tier 0 (~15 %: room for one hit in four, at most 4 M), tier 1
+  // (~4 %: one in eight, at most 2 M) and tier 2 (~0.7 %: one in 32, at most 1 M); rs[t] = dumps of tier t
   const GapResume no_resume{nullptr, nullptr, nullptr, 0};
-  GapResume rs[2] = {no_resume, no_resume};
+  GapResume rs[3] = {no_resume, no_resume, no_resume};
   if (!getenv("PRB_GAPPED_NO_RESUME")) {
-    rs[0].cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
-    rs[1].cap = (int32_t)std::min<int64_t>(nung / 32 + 1024, 1 << 20);
+    rs[0].cap = (int32_t)std::min<int64_t>(nung / 4 + 1024, 4 << 20);
+    rs[1].cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
+    rs[2].cap = (int32_t)std::min<int64_t>(nung / 32 + 1024, 1 << 20);
     if (const char *e = getenv("PRB_GAPPED_RESUME_CAP")) // testing: pools that run out (those hits are redone instead)
-      rs[0].cap = rs[1].cap = std::max(1, atoi(e));
-    if ((rc = w.resumeSlot.ensure((size_t)nung * 8)) || (rc = w.resumeCount.ensure(16)) ||
-        (rc = w.resumePool.ensure((size_t)rs[0].cap * gapped_resume_bytes(0))) ||
-        (rc = w.resumePool2.ensure((size_t)rs[1].cap * gapped_resume_bytes(1))))
-      return rc;
-    rs[0].slot = w.resumeSlot.as<int32_t>();
-    rs[1].slot = w.resumeSlot.as<int32_t>() + nung;
-    rs[0].pool = w.resumePool.as<uint8_t>();
-    rs[1].pool = w.resumePool2.as<uint8_t>();
-    rs[0].count = w.resumeCount.as<uint32_t>();
-    rs[1].count = w.resumeCount.as<uint32_t>() + 1;
-    PRB_HIP(hipMemsetAsync(w.resumeCount.p, 0, 8, ctx->stream));
-    PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 8, ctx->stream));
+      rs[0].cap = rs[1].cap = rs[2].cap = std::max(1, atoi(e));
+    DevBuf *pools[3] = {&w.resumePool, &w.resumePool2, &w.resumePool3};
+    if ((rc = w.resumeSlot.ensure((size_t)nung * 4 * 3)) || (rc = w.resumeCount.ensure(16))) return rc;
+    for (int t = 0; t < 3; t++) {
+      if ((rc = pools[t]->ensure((size_t)rs[t].cap * gapped_resume_bytes(t)))) return rc;
+      rs[t].slot = w.resumeSlot.as<int32_t>() + (size_t)t * nung;
+      rs[t].pool = pools[t]->as<uint8_t>();
+      rs[t].count = w.resumeCount.as<uint32_t>() + t;
+    }
+    PRB_HIP(hipMemsetAsync(w.resumeCount.p, 0, 16, ctx->stream));
+    PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 4 * 3, ctx->stream));
   }
-  static const char *const kTierTimer[4] = {"gapped", "gapped_t1", "gapped_t2", "gapped_slow"};
+  static const char *const kTierTimer[5] = {"gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow"};
   {
     const uint32_t *cur = nullptr; // all of U
     int64_t m = nung;
@@ -1004,7 +1003,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     for (size_t c = 0; c < cascade.size() && m > 0; c++) {
       const int tier = cascade[c];
       if ((rc = ctx->time_begin())) return rc;
-      if (tier == 3) {
+      if (tier == kWaveTier) {
         hs->slow_hits += m;
         ctx->slow_hits += m;
         if ((rc = run_wave(0, cur, m, bufs[nb], nullptr))) return rc;
@@ -1012,8 +1011,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                   w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
-                                  w.count.as<unsigned long long>() + 1, tier == 1 ? rs[0] : tier == 2 ? rs[1] : no_resume,
-                                  tier == 0 ? rs[0] : tier == 1 ? rs[1] : no_resume, ctx->stream));
+                                  w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,
+                                  tier <= 2 ? rs[tier] : no_resume, ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
         cur = bufs[nb];
@@ -1078,20 +1077,20 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.first.as<uint8_t>(), w.ntrace.as<int32_t>(),
                              w.tierOf.as<uint8_t>(), w.trace.as<uint16_t>(), w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(),
                              ctx->stream));
-    std::vector<uint32_t> tlist[4];
-    std::vector<int64_t> toff[4];
+    std::vector<uint32_t> tlist[kWaveTier + 1];
+    std::vector<int64_t> toff[kWaveTier + 1];
     const bool no_slots = getenv("PRB_TRACE_NO_SLOTS") != nullptr; // testing: re-extend every final hit as well
     const char *cap_env = getenv("PRB_TRACE_SLOT_CAP");               // testing: pretend the slots are shorter
     const int slot_cap = cap_env ? std::min(kTraceCap, atoi(cap_env)) : kTraceCap;
     for (int64_t i = 0; i < nfin; i++) {
-      const int t = tier_fin[i] & 3;
-      if (no_slots || t == 3 || (int)(ntr[i] & 0xFFFF) > slot_cap || (int)(ntr[i] >> 16) > slot_cap) {
+      const int t = std::min<int>(tier_fin[i] & 7, kWaveTier);
+      if (no_slots || t == kWaveTier || (int)(ntr[i] & 0xFFFF) > slot_cap || (int)(ntr[i] >> 16) > slot_cap) {
         tlist[t].push_back(pre[i]);
         toff[t].push_back(off[i]);
       }
     }
     bool any_rerun = false;
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t <= kWaveTier; t++) {
       if (tlist[t].empty()) continue;
       const int64_t m = (int64_t)tlist[t].size();
       if (!any_rerun) {
@@ -1102,7 +1101,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = w.bpOff2.ensure((size_t)m * 8)) || (rc = w.subset2.ensure((size_t)m * 4))) return rc;
       PRB_HIP(hipMemcpyAsync(w.bpOff2.p, toff[t].data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
       PRB_HIP(hipMemcpyAsync(w.subset2.p, tlist[t].data(), (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream));
-      if (t == 3) {
+      if (t == kWaveTier) {
         if ((rc = run_wave(2, w.subset2.as<uint32_t>(), m, nullptr, w.bpOff2.as<int64_t>()))) return rc;
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,

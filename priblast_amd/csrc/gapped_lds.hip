@@ -13,9 +13,12 @@
 // i.e. "first candidate in list order wins under strict <"; the scalars of the recurrence are
 // kept redundantly in every lane.  The reference's growing 100x100 Cell matrix never exists.
 //
-// Two instantiations:
-//   k_gapped_lds   G = 16, state in LDS; tier 1 (64 anti-diagonals, 96 cells: 2.4 KB per hit, 64 hits
-//                  per CU) takes ~98.6 % of the hits, tier 2 (128, 448: 9.6 KB per hit) the next ~1.4 %
+// Two forms, a cascade of five kernels (a hit goes on to the next one when it outgrows the state a
+// kernel has room for; the LDS tiers hand their state over, so the next tier continues instead of
+// starting again):
+//   k_gapped_lds   state in LDS.  Tier 0: 8 lanes per hit, 30 anti-diagonals and 48 cells per
+//                  direction (1.26 KB per hit, 128 hits and 4 wavefronts per SIMD on a CU); tier 1:
+//                  8 lanes, 40 / 64; tier 2: 16 lanes, 64 / 120; tier 3: a wavefront per hit, 128 / 512
 //   k_gapped_wave  G = 64, state in HBM scratch sized at run time: the rest
 // Why: an extension is small (median 16 anti-diagonals, ~10 filled cells per direction) but its
 // cell list is re-read for every filled cell; per-thread scratch in HBM made every access a
@@ -30,7 +33,7 @@ namespace prb {
 // Developer-only cycle breakdown of the gapped kernel (make PROF=1 builds libpriblast_hip_prof.so;
 // tools/gapped_profile.py reads it).  Not part of the product build.
 #ifdef PRB_GAP_PROFILE
-__device__ unsigned long long g_gap_prof[8 * 16]; // [tier * 2 + (mode != 0)][region]
+__device__ unsigned long long g_gap_prof[10 * 16]; // [tier * 2 + (mode != 0)][region]
 struct GapProf {
   unsigned long long last, acc[16];
   __device__ __forceinline__ void start() {
@@ -65,21 +68,27 @@ constexpr int kInitStage = 16; // extension lengths whose accessibility sums dir
 // LDS tiers: lanes per hit, (anti-diagonals, filled cells) per direction, groups (= hits) per
 // workgroup, staged extension lengths (<= lanes per hit)
 struct Rec32;
-struct Tier0 { // 1.6 KB per hit, 3 workgroups of 256 threads (32 hits) per CU
-  static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
-  static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by tier 1
+struct Tier0 { // 1.26 KB per hit, 4 workgroups of 256 threads (32 hits) per CU = 4 wavefronts per SIMD
+  static constexpr int kG = 8, kCapD = 30, kCapR = 48, kGroups = 32, kWavesPerSimd = 4, kWgPerCu = 4;
+  static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by the next tier
   static constexpr bool kResumes = false;
 };
-struct Tier1 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
-  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
+struct Tier1 { // 1.65 KB per hit, 3 workgroups of 256 threads (32 hits) per CU: the hits a little too long for tier 0
+  static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
   static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 0, leaves its own
   using From = Tier0;
   using FromRec = Rec32;
 };
-struct Tier2 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
-  static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
-  static constexpr bool kResumable = false, kResumes = true; // continues the state dumps of tier 1
+struct Tier2 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
+  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 1, leaves its own
   using From = Tier1;
+  using FromRec = Rec32;
+};
+struct Tier3 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
+  static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
+  static constexpr bool kResumable = false, kResumes = true; // continues the state dumps of tier 2
+  using From = Tier2;
   using FromRec = Rec32;
 };
 
@@ -99,7 +108,7 @@ struct Rec32 {
   static __device__ __forceinline__ int qa(word v) { return (v >> 24) & 7; }
   static __device__ __forceinline__ int da(word v) { return (v >> 27) & 7; }
 };
-struct Rec32W { // tier 2: no room for the neighbour bases, they are read from the staged windows
+struct Rec32W { // tier 3: no room for the neighbour bases, they are read from the staged windows
   using word = uint32_t; // i:8 | j:8 | pred:9 | type:3
   static constexpr bool kBases = false;
   static __device__ __forceinline__ word pack(int i, int j, int pred, int type, int, int) {
@@ -126,7 +135,10 @@ struct Rec64 {
   static __device__ __forceinline__ int qa(word v) { return (int)((v >> 36) & 0xF); }
   static __device__ __forceinline__ int da(word v) { return (int)((v >> 40) & 0xF); }
 };
-static_assert(Tier2::kCapD + 16 <= 255 && Tier2::kCapR <= 512 && Tier0::kCapR * 8 >= 6 * kInitStage * 4 && Tier1::kCapD + 16 <= 127 && Tier1::kCapR <= 127, "Rec32 field widths");
+static_assert(Tier3::kCapD + 16 <= 255 && Tier3::kCapR <= 512 && Tier0::kCapR * 8 >= 6 * kInitStage * 4 && Tier2::kCapD + 16 <= 127 && Tier2::kCapR <= 127, "Rec32 field widths");
+static_assert(Tier0::kCapD <= Tier1::kCapD && Tier1::kCapD <= Tier2::kCapD && Tier2::kCapD <= Tier3::kCapD && Tier0::kCapR <= Tier1::kCapR &&
+                  Tier1::kCapR <= Tier2::kCapR && Tier2::kCapR <= Tier3::kCapR,
+              "a tier continues the dumps of the one before it");
 
 template <class T, class Rec> struct LdsState {
   double eq[T::kCapD], ed[T::kCapD];
@@ -225,10 +237,14 @@ struct DirResult {
 };
 
 // What a group knows about the hit it is extending.
+// The arrays a hit's sequences live in (wave-uniform); a hit only carries its offsets into them.
+struct SeqBases {
+  const uint8_t *qenc;
+  const float *qacc, *qcond, *dacc, *dcond;
+};
 struct HitCtx {
   int64_t x, out0;
-  const uint8_t *qs;
-  const float *qacc, *qcond, *dacc, *dcond;
+  int64_t qo, dbase; // query: offset of its codes / accessibilities; database sequence: offset of its accessibilities
   HitState h;
   int query, id, qn;
   int diag_q, diag_d, diag_len, ndiag, nleft, nright;
@@ -239,13 +255,34 @@ struct HitCtx {
 // after direction 0, so the next kernel of the cascade only has to extend the other direction
 constexpr uint8_t kResumeMark = 0x40;
 
-// The scalars of one direction's recurrence (kept redundantly in every lane of the group).
+// Where a direction starts (gapped_extension.cpp:88-128), from the hit as the direction found it:
+// the outermost pair on that side, and the database sequence's accessibility indices.
+struct DirOrigin {
+  int q_start, id_start, id_end;
+  int64_t db_start;
+};
+__device__ __forceinline__ DirOrigin dir_origin(const HitState &h, int flag) {
+  DirOrigin o;
+  if (flag == 0) {
+    o.q_start = h.q_sp;
+    o.db_start = h.db_sp;
+  } else {
+    o.q_start = h.q_sp + h.q_len - 1;
+    o.db_start = (int64_t)h.db_sp + h.db_len - 1;
+  }
+  o.id_start = h.id_start;
+  o.id_end = h.id_start + h.db_len - 1;
+  return o;
+}
+
+// The scalars of one direction's recurrence (kept redundantly in every lane of the group).  Only
+// what cannot be had from the hit (HitCtx::h stays as the direction found it until dir_finish) and
+// from the cell of the minimum: registers decide how many hits a compute unit extends at a time.
 struct DirState {
-  double min_e, first_a, min_a;
+  double min_e;
   double acc_prev; // lane 0: eq[length-2]; lane 1 (or 0 when G == 1): ed[length-2]
-  int64_t db_start, min_db_start;
-  int q_start, id_start, id_end, min_q_start, q_length, db_length, min_q_len, min_db_len, min_id_start;
-  int length, min_length, best, nrec, lo, tq0, td0;
+  int min_ci, min_cj; // the cell of the minimum (0, 0: the start)
+  int length, best, nrec, lo, tq0, td0;
   int staged; // eq[] / ed[] are computed for the extension lengths 1..staged
   // set when a resumable kernel runs out of cells in the middle of an anti-diagonal: the chunk to
   // go on with, and the end of the candidate window of that anti-diagonal (0: not in the middle)
@@ -257,17 +294,18 @@ struct DirState {
 // lengths from L0 on: the terms are fetched in parallel into the float scratch sf(term, t),
 // the sums are sequential (lane 0: query side -> eq[], lane 1: db side -> ed[]).
 template <int G, bool kLds, class Store>
-__device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, const Store &S, int gl, DirState &d, int L0,
+__device__ __forceinline__ void stage_acc(const SeqBases &sb, const HitCtx &c, int flag, int delta, const Store &S, int gl, DirState &d, int L0,
                                           int nb, float *scratch /* [6][nb], or nullptr: no parallel fetch */) {
-  const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
+  const float *qacc = sb.qacc + c.qo, *qcond = sb.qcond + c.qo, *dacc = sb.dacc + c.dbase, *dcond = sb.dcond + c.dbase;
+  const DirOrigin og = dir_origin(c.h, flag);
   // term k of length len: query side k = 0..2, db side k = 3..5
   auto term = [&](int k, int len) -> float {
     if (flag == 0) {
-      const int p = d.q_start - len;
-      return k == 0 ? qacc[p] : k == 1 ? qacc[p + 1] : k == 2 ? qcond[p + delta] : dcond[d.id_end + len];
+      const int p = og.q_start - len;
+      return k == 0 ? qacc[p] : k == 1 ? qacc[p + 1] : k == 2 ? qcond[p + delta] : dcond[og.id_end + len];
     }
-    const int p = d.id_start - len;
-    return k == 0 ? qcond[d.q_start + len] : k == 3 ? dacc[p] : k == 4 ? dacc[p + 1] : dcond[p + delta];
+    const int p = og.id_start - len;
+    return k == 0 ? qcond[og.q_start + len] : k == 3 ? dacc[p] : k == 4 ? dacc[p + 1] : dcond[p + delta];
   };
   if (scratch) {
     for (int t = gl; t < nb; t += G) {
@@ -328,10 +366,11 @@ __device__ __forceinline__ void stage_acc(const HitCtx &c, int flag, int delta, 
 // registers (all loads in flight together), then the group walks the 16 lengths in order, the
 // terms coming from their lanes by shuffle; every lane carries both running sums.
 template <int G, bool kLds, class Store>
-__device__ __forceinline__ void stage_acc_regs(const HitCtx &c, int flag, int delta, const Store &S, int gl, int gbase,
+__device__ __forceinline__ void stage_acc_regs(const SeqBases &sb, const HitCtx &c, int flag, int delta, const Store &S, int gl, int gbase,
                                                DirState &d, int L0) {
   constexpr int nb = kInitStage, per = (nb + G - 1) / G;
-  const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
+  const float *qacc = sb.qacc + c.qo, *qcond = sb.qcond + c.qo, *dacc = sb.dacc + c.dbase, *dcond = sb.dcond + c.dbase;
+  const DirOrigin og = dir_origin(c.h, flag);
   float t0[per], t1[per], t2[per], t3[per]; // flag 0: query acc, acc+1, cond | db cond;  flag 1: query cond | db acc, acc+1, cond
 #pragma unroll
   for (int r = 0; r < per; r++) {
@@ -340,19 +379,19 @@ __device__ __forceinline__ void stage_acc_regs(const HitCtx &c, int flag, int de
     if (t < nb) {
       if (len < d.tq0) {
         if (flag == 0) {
-          const int p = d.q_start - len;
+          const int p = og.q_start - len;
           t0[r] = qacc[p];
           t1[r] = qacc[p + 1];
           t2[r] = qcond[p + delta];
         } else {
-          t0[r] = qcond[d.q_start + len];
+          t0[r] = qcond[og.q_start + len];
         }
       }
       if (len < d.td0) {
         if (flag == 0) {
-          t3[r] = dcond[d.id_end + len];
+          t3[r] = dcond[og.id_end + len];
         } else {
-          const int p = d.id_start - len;
+          const int p = og.id_start - len;
           t1[r] = dacc[p];
           t2[r] = dacc[p + 1];
           t3[r] = dcond[p + delta];
@@ -391,16 +430,17 @@ __device__ __forceinline__ void stage_acc_regs(const HitCtx &c, int flag, int de
 // first 0 at t >= 1 is where the reference sets max_q_extension / max_db_extension (:131-154).
 // Also clears the three predecessor-type rows.
 template <int G, bool kLds, class Store>
-__device__ __forceinline__ void stage_windows(const HitCtx &c, int flag, const uint8_t *ds, int64_t dn, const Store &S, int gl,
+__device__ __forceinline__ void stage_windows(const SeqBases &sb, const HitCtx &c, int flag, const uint8_t *ds, int64_t dn, const Store &S, int gl,
                                               DirState &d, bool clear_rows = true) {
-  const uint8_t *qs = c.qs;
+  const uint8_t *qs = sb.qenc + c.qo;
   const int qn = c.qn;
   const int wn = S.win_len();
+  const DirOrigin og = dir_origin(c.h, flag);
   d.tq0 = wn;
   d.td0 = wn;
   for (int t = gl; t < wn; t += G) {
-    const int64_t qp = flag == 0 ? (int64_t)d.q_start - t : (int64_t)d.q_start + t;
-    const int64_t dp = flag == 0 ? d.db_start - t : d.db_start + t;
+    const int64_t qp = flag == 0 ? (int64_t)og.q_start - t : (int64_t)og.q_start + t;
+    const int64_t dp = flag == 0 ? og.db_start - t : og.db_start + t;
     const int qc = (qp >= 0 && qp < qn) ? get_char(qs, qp) : 0;
     const int dc = (dp >= 0 && dp < dn) ? get_char(ds, dp) : 0;
     S.qb(t) = (uint8_t)qc;
@@ -427,42 +467,24 @@ __device__ __forceinline__ void stage_windows(const HitCtx &c, int flag, const u
 // along both strands, so GetBPType / CheckHelixLength / LoopEnergy never go back to HBM),
 // dir_step (one anti-diagonal; true when the direction is finished) and dir_finish.
 template <int G, bool kLds, class Store>
-__device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c, int flag, const uint8_t *ds, int64_t dn,
+__device__ __forceinline__ void dir_init(const SearchConst &sc, const SeqBases &sb, const HitCtx &c, int flag, const uint8_t *ds, int64_t dn,
                                          const Store &S, int gl, int delta, DirState &d) {
   using R = typename Store::R;
-  const HitState &h = c.h;
-  d.min_e = h.e_tot;
-  d.first_a = h.e_acc;
-  d.min_a = d.first_a;
-  if (flag == 0) {
-    d.q_start = h.q_sp;
-    d.db_start = h.db_sp;
-  } else {
-    d.q_start = h.q_sp + h.q_len - 1;
-    d.db_start = (int64_t)h.db_sp + h.db_len - 1;
-  }
-  d.id_start = h.id_start;
-  d.id_end = d.id_start + h.db_len - 1;
-  d.min_q_start = d.q_start;
-  d.min_db_start = d.db_start;
-  d.q_length = h.q_len;
-  d.db_length = h.db_len;
-  d.min_q_len = d.q_length;
-  d.min_db_len = d.db_length;
-  d.min_id_start = d.id_start;
+  d.min_e = c.h.e_tot;
+  d.min_ci = 0;
+  d.min_cj = 0;
   d.length = 0;
-  d.min_length = 0;
   d.best = 0;
   d.overflow = false;
   d.resume_i0 = 0;
   d.resume_dstart = 0;
 
-  stage_windows<G, kLds>(c, flag, ds, dn, S, gl, d);
+  stage_windows<G, kLds>(sb, c, flag, ds, dn, S, gl, d);
   // accessibility sums of the first kInitStage lengths (nearly every direction ends within them);
   // the cell list is still empty, so its energies' storage serves as the float scratch
   d.acc_prev = 0;
   {
-    stage_acc<G, kLds>(c, flag, delta, S, gl, d, 1, kInitStage, reinterpret_cast<float *>(&S.hyb(0)));
+    stage_acc<G, kLds>(sb, c, flag, delta, S, gl, d, 1, kInitStage, reinterpret_cast<float *>(&S.hyb(0)));
   }
   int type0 = bp_type(sc, S.qb(0), S.db(0));
   if (flag == 0) type0 = rtype_of(type0);
@@ -477,12 +499,11 @@ __device__ __forceinline__ void dir_init(const SearchConst &sc, const HitCtx &c,
 }
 
 template <int G, bool kLds, class Store>
-__device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o, const HitCtx &c, int flag, const Store &S,
+__device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &sb, const ExtOpts &o, const HitCtx &c, int flag, const Store &S,
                                          int gl /* lane in group */, int gbase /* first lane of the group in its wavefront */,
                                          DirState &d, GapProf &prof) {
   using R = typename Store::R;
   const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
-  const float *qacc = c.qacc, *qcond = c.qcond, *dacc = c.dacc, *dcond = c.dcond;
   const bool mid = d.resume_i0 != 0; // continuing an anti-diagonal that a smaller kernel could not finish
   if (!mid) {
     if (d.length >= S.cap_d()) { // no room for another anti-diagonal: the state stays that of the last complete one
@@ -497,7 +518,7 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
   const int cur = d.length % 3, d2 = (d.length + 1) % 3; // d2 = (d.length - 2) mod 3
   if (!mid) {
     // cumulative accessibility change beyond the lengths prepared so far (one direction in ten gets here)
-    if (d.length > d.staged) stage_acc_regs<G, kLds>(c, flag, delta, S, gl, gbase, d, d.length);
+    if (d.length > d.staged) stage_acc_regs<G, kLds>(sb, c, flag, delta, S, gl, gbase, d, d.length);
     GP_MARK(1);
     GP_COUNT(10);
     // recycle the row of anti-diagonal d.length-3 for this one
@@ -517,6 +538,75 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
   const int i_lo = mid ? d.resume_i0 : (d.length - max_d > 1 ? d.length - max_d : 1);
   const int i_hi = max_q < d.length - 1 ? max_q : d.length - 1;
   d.resume_i0 = 0;
+
+  // One filled cell (ci, d.length - ci) of pair type ctype: its best predecessor among the live
+  // candidates [d.lo, dstart), the new record, the running minimum.  Returns the predecessor's type
+  // (what the reference stores as Cell::type), or -1 when the cell list is full.
+  auto fill_cell = [&](int ci, int ctype) -> int {
+    GP_COUNT(12);
+    const int cj = d.length - ci;
+    // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
+    const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
+    const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1); // needed after the scan; fetched behind it
+    const int fq = S.qb(ci + 1), fd = S.db(cj + 1);        // likewise: the new record's far-side bases
+    double bte = 1000000.0;                                // INF
+    int bkp = d.lo << 3; // candidate index << 3 | its type (0: none looked at), so the type comes out of the reduction
+    // (the records of the next round are fetched while this round's energies are looked up)
+    typename R::word vn = 0;
+    double hn = 0;
+    if (d.lo + gl < dstart) {
+      vn = S.info(d.lo + gl);
+      hn = S.hyb(d.lo + gl);
+    }
+    for (int k0 = d.lo; k0 < dstart; k0 += G) {
+      GP_COUNT(13);
+      const int k = k0 + gl;
+      const auto v = vn;
+      const double hk = hn;
+      if (k + G < dstart) {
+        vn = S.info(k + G);
+        hn = S.hyb(k + G);
+      }
+      if (k < dstart) {
+        const int ri = R::i(v), rj = R::j(v);
+        if (ri < ci && rj < cj) {
+          // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
+          // offsets (ri, rj) and (ci, cj) from the start
+          const int rq = R::kBases ? R::qa(v) : (int)S.qb(ri + 1), rd = R::kBases ? R::da(v) : (int)S.db(rj + 1);
+          double te;
+          if (flag == 0) te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, nq, nd, rq, rd);
+          else te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, rq, rd, nq, nd);
+          te += hk;
+          if (te < bte) {
+            bte = te;
+            bkp = (k << 3) | R::type(v);
+          }
+        }
+      }
+    }
+    GP_MARK(4);
+    group_min<G>(bte, bkp); // "first candidate in list order wins under strict <"
+    GP_MARK(5);
+    if (d.nrec >= S.cap_r()) return -1;
+    int bk = bkp >> 3, ptype = bkp & 7;
+    if (d.lo >= dstart) bk = 0;                  // empty window: the reference reads stem_candidate[0] of an empty list
+    if (ptype == 0) ptype = R::type(S.info(bk)); // no candidate qualified: the type of that default entry
+    if (gl == 0) {
+      S.hyb(d.nrec) = bte;
+      S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
+    }
+    const double ie = eq_c + ed_c + bte;
+    if (ie < d.min_e) { // (:260-278; everything else the reference notes down here follows from the cell)
+      d.min_e = ie;
+      d.best = d.nrec;
+      d.min_ci = ci;
+      d.min_cj = cj;
+    }
+    d.nrec++;
+    GP_MARK(6);
+    return ptype;
+  };
+
   for (int i0 = i_lo; i0 <= i_hi && !d.overflow; i0 += G) {
     const int i = i0 + gl, j = d.length - i;
     int type1 = 0;
@@ -552,107 +642,44 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const ExtOpts &o
       break;
     }
     while (vmask) { // filled cells of this chunk, ascending i
-      GP_COUNT(12);
       const int b = __builtin_ctzll(vmask);
       vmask &= vmask - 1;
-      const int ci = i0 + b, cj = d.length - ci;
+      const int ci = i0 + b;
       const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
                         (int)(((tb2 >> (gbase + b)) & 1) << 2);
-      // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
-      const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
-      const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1); // needed after the scan; fetched behind it
-      const int fq = S.qb(ci + 1), fd = S.db(cj + 1);        // likewise: the new record's far-side bases
-      double bte = 1000000.0;                                // INF
-      int bkp = d.lo << 3; // candidate index << 3 | its type (0: none looked at), so the type comes out of the reduction
-      // (the records of the next round are fetched while this round's energies are looked up)
-      typename R::word vn = 0;
-      double hn = 0;
-      if (d.lo + gl < dstart) {
-        vn = S.info(d.lo + gl);
-        hn = S.hyb(d.lo + gl);
-      }
-      for (int k0 = d.lo; k0 < dstart; k0 += G) {
-        GP_COUNT(13);
-        const int k = k0 + gl;
-        const auto v = vn;
-        const double hk = hn;
-        if (k + G < dstart) {
-          vn = S.info(k + G);
-          hn = S.hyb(k + G);
-        }
-        if (k < dstart) {
-          const int ri = R::i(v), rj = R::j(v);
-          if (ri < ci && rj < cj) {
-            // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
-            // offsets (ri, rj) and (ci, cj) from the start
-            const int rq = R::kBases ? R::qa(v) : (int)S.qb(ri + 1), rd = R::kBases ? R::da(v) : (int)S.db(rj + 1);
-            double te;
-            if (flag == 0) te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, nq, nd, rq, rd);
-            else te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, rq, rd, nq, nd);
-            te += hk;
-            if (te < bte) {
-              bte = te;
-              bkp = (k << 3) | R::type(v);
-            }
-          }
-        }
-      }
-      GP_MARK(4);
-      group_min<G>(bte, bkp); // "first candidate in list order wins under strict <"
-      GP_MARK(5);
-      if (d.nrec >= S.cap_r()) {
+      const int ptype = fill_cell(ci, ctype);
+      if (ptype < 0) {
         d.overflow = true;
         break;
       }
-      int bk = bkp >> 3, ptype = bkp & 7;
-      if (d.lo >= dstart) bk = 0;                  // empty window: the reference reads stem_candidate[0] of an empty list
-      if (ptype == 0) ptype = R::type(S.info(bk)); // no candidate qualified: the type of that default entry
-      if (gl == 0) {
-        S.hyb(d.nrec) = bte;
-        S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
-        S.ptab(cur, ci) = (uint8_t)ptype;
-      }
-      const double ie = eq_c + ed_c + bte;
-      if (ie < d.min_e) {
-        d.min_e = ie;
-        d.min_a = d.first_a + eq_c + ed_c;
-        d.min_length = d.length;
-        d.best = d.nrec;
-        if (flag == 0) {
-          d.min_q_start = d.q_start - ci;
-          d.min_db_start = d.db_start - cj;
-        } else {
-          d.min_id_start = d.id_start - cj;
-        }
-        d.min_q_len = d.q_length + ci;
-        d.min_db_len = d.db_length + cj;
-      }
-      d.nrec++;
-      GP_MARK(6);
+      if (gl == 0) S.ptab(cur, ci) = (uint8_t)ptype;
     }
     group_sync<kLds>();
     GP_MARK(3);
   }
   if (d.overflow) return true;
-  if (d.length - d.min_length >= drop) return true;
+  if (d.length - (d.min_ci + d.min_cj) >= drop) return true;
   if (!q_open && !d_open) return true;
   return false;
 }
 
-__device__ __forceinline__ DirResult dir_finish(const DirState &d, HitState &h, int flag) {
+// The hit after the direction (:300-318): grown by the cell of the minimum, if there is one.
+template <class Store> __device__ __forceinline__ DirResult dir_finish(const DirState &d, HitState &h, int flag, const Store &S) {
   DirResult r;
   r.overflow = d.overflow;
-  r.best = (d.q_length - d.min_q_len != 0 && d.db_length - d.min_db_len != 0) ? d.best : 0;
-  h.id_start = d.min_id_start;
-  if (flag == 0) {
-    h.q_sp = d.min_q_start;
-    h.db_sp = (int)d.min_db_start;
+  r.best = d.min_ci != 0 ? d.best : 0; // (a filled cell has i >= 1 and j >= 1)
+  if (d.min_ci != 0) {
+    h.e_acc = h.e_acc + S.eq(d.min_ci - 1) + S.ed(d.min_cj - 1); // first_accessibility + accQ[i-1] + accDb[j-1] (:266)
+    if (flag == 0) {
+      h.q_sp -= d.min_ci;
+      h.db_sp -= d.min_cj;
+    } else {
+      h.id_start -= d.min_cj;
+    }
+    h.q_len += d.min_ci;
+    h.db_len += d.min_cj;
   }
-  h.q_len = d.min_q_len;
-  h.db_len = d.min_db_len;
-  h.e_tot = d.min_e;
-  h.e_acc = d.min_a;
-  h.e_hyb = d.min_e - d.min_a;
+  h.e_tot = d.min_e; // (hybridization energy = h.e_tot - h.e_acc, taken where the hit is written)
   return r;
 }
 
@@ -678,14 +705,14 @@ struct GapArgs {
   GapResume rin, rout;
 };
 
-// A state dump: everything tier 1 needs to go on where tier 0 ran out of capacity.
+// A state dump: everything the next tier needs to go on where this one ran out of capacity.
 struct ResumeHeader {
   DirState d;       // lane 0's copy, as of the last complete anti-diagonal
   double acc_prev1; // lane 1's accumulator (the db-side chain)
   HitState h;       // the hit as the running direction found it
   int32_t flag, nleft;
 };
-// slot size for dumps of tier T (tier 0 dumps are read by tier 1, tier 1 dumps by tier 2)
+// slot size for dumps of tier T (read by tier T + 1)
 template <class T, class Rec> constexpr size_t resume_bytes() {
   return (sizeof(ResumeHeader) + sizeof(LdsState<T, Rec>) + 63) & ~(size_t)63;
 }
@@ -713,6 +740,7 @@ __device__ __forceinline__ void resume_dump(const GapResume &ro, const HitCtx &c
   }
   uint32_t *w = reinterpret_cast<uint32_t *>(dst + sizeof(ResumeHeader));
   const uint32_t *src = reinterpret_cast<const uint32_t *>(&st);
+#pragma unroll 2 // (rare path: keep its registers out of the way)
   for (int t = gl; t < (int)(sizeof(LdsState<T, Rec>) / 4); t += G) w[t] = src[t];
 }
 
@@ -731,7 +759,8 @@ __device__ __forceinline__ void resume_load(const GapResume &ri, int slot, const
   c.nleft = H->nleft;
   flag = H->flag;
   const LdsState<TS, RecS> *s0 = reinterpret_cast<const LdsState<TS, RecS> *>(src + sizeof(ResumeHeader));
-  stage_windows<G, true>(c, flag, a.pg.seqs, a.pg.nchars, S, gl, d); // also clears the rows
+  stage_windows<G, true>(SeqBases{a.qb.enc, a.qb.acc, a.qb.cond, a.pg.acc, a.pg.cond}, c, flag, a.pg.seqs, a.pg.nchars, S, gl,
+                         d); // also clears the rows
   for (int t = gl; t < TS::kCapD; t += G) {
     S.eq(t) = s0->eq[t];
     S.ed(t) = s0->ed[t];
@@ -757,15 +786,10 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
   const int64_t x = a.subset ? (int64_t)a.subset[w] : w;
   c.x = x;
   c.query = a.in.query[x];
-  const int64_t qo = a.qb.off[c.query];
-  c.qs = a.qb.enc + qo;
+  c.qo = a.qb.off[c.query];
   c.qn = a.qb.len[c.query] + 1;
-  c.qacc = a.qb.acc + qo;
-  c.qcond = a.qb.cond + qo;
   c.id = a.in.db_id[x];
-  const int64_t base = (int64_t)a.pg.start_pos[c.id] - c.id;
-  c.dacc = a.pg.acc + base;
-  c.dcond = a.pg.cond + base;
+  c.dbase = (int64_t)a.pg.start_pos[c.id] - c.id;
   HitState &h = c.h;
   h.q_sp = a.in.q_sp[x];
   h.db_sp = a.in.db_sp[x];
@@ -774,14 +798,13 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
   h.id_start = a.in.db_id_start[x];
   h.e_tot = a.in.e_tot[x];
   h.e_acc = a.in.e_acc[x];
-  h.e_hyb = a.in.e_hyb[x];
   c.diag_q = h.q_sp; // the ungapped region
   c.diag_d = h.db_sp;
   c.diag_len = US(h.q_len);
   c.ndiag = 0;
   if (kMode != 0) // GetBasePair, rna_interaction_search.cpp:371-385 (every lane counts; cheap)
     for (int t = 0; t < c.diag_len; t++)
-      c.ndiag += diag_pairs(sc, c.qs[c.diag_q + t], a.pg.seqs[c.diag_d + t]);
+      c.ndiag += diag_pairs(sc, a.qb.enc[c.qo + c.diag_q + t], a.pg.seqs[c.diag_d + t]);
   c.unsorted = kMode != 0 && a.first_flag && a.first_flag[x]; // hit 0 keeps raw pair order (:314-317)
   c.out0 = kMode == 2 ? a.bp_off[w] : 0;
   c.ovf = false;
@@ -796,7 +819,6 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
     h.id_start = a.out.db_id_start[x];
     h.e_tot = a.out.e_tot[x];
     h.e_acc = a.out.e_acc[x];
-    h.e_hyb = a.out.e_hyb[x];
     c.nleft = a.bp_count[x] & 0xFFFF;
     c.resumed = true;
   }
@@ -806,8 +828,8 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
 // predecessors.  The extension pass leaves the chain in the hit's trace slot, so that the base
 // pairs of the few hits that survive the final filter can be written without extending them again.
 template <int kMode, bool kLds, class Store>
-__device__ __forceinline__ void hit_dir_done(const GapArgs &a, HitCtx &c, int flag, const DirState &d, const DirResult &r,
-                                             const Store &S, int gl) {
+__device__ __forceinline__ void hit_dir_done(const GapArgs &a, HitCtx &c, int flag, const DirOrigin &og /* before dir_finish */,
+                                             const DirResult &r, const Store &S, int gl) {
   using R = typename Store::R;
   c.ovf = r.overflow;
   if (c.ovf) return;
@@ -827,12 +849,12 @@ __device__ __forceinline__ void hit_dir_done(const GapArgs &a, HitCtx &c, int fl
       int64_t pos;
       int qv, dv;
       if (flag == 0) { // emitted outermost first = ascending positions
-        qv = d.q_start - R::i(v);
-        dv = (int)(d.db_start - R::j(v));
+        qv = og.q_start - R::i(v);
+        dv = (int)(og.db_start - R::j(v));
         pos = c.unsorted ? c.out0 + c.ndiag + t : c.out0 + t;
       } else { // emitted outermost first = descending positions
-        qv = d.q_start + R::i(v);
-        dv = (int)(d.db_start + R::j(v));
+        qv = og.q_start + R::i(v);
+        dv = (int)(og.db_start + R::j(v));
         pos = c.unsorted ? c.out0 + c.ndiag + c.nleft + t : c.out0 + c.nleft + c.ndiag + (cnt - 1 - t);
       }
       a.bp_out[2 * pos] = qv;
@@ -847,7 +869,7 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
   if (gl != 0) return;
   const SearchConst &sc = a.sc;
   const HitState &h = c.h;
-  const uint8_t *ds = a.pg.seqs;
+  const uint8_t *ds = a.pg.seqs, *qs = a.qb.enc + c.qo;
   if (kMode == 0) {
     a.overflow[w] = c.ovf ? 1 : 0;
     if (c.ovf && flag == 1) { // direction 0 is done (c.h is its result): leave it for the next kernel
@@ -858,7 +880,7 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
       a.out.db_len[x] = h.db_len;
       a.out.db_id_start[x] = h.id_start;
       a.out.e_acc[x] = h.e_acc;
-      a.out.e_hyb[x] = h.e_hyb;
+      a.out.e_hyb[x] = h.e_tot - h.e_acc;
       a.out.e_tot[x] = h.e_tot;
       a.bp_count[x] = c.nleft;
       a.tier_out[x] = kResumeMark;
@@ -868,10 +890,10 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
       a.tier_out[x] = (uint8_t)a.tier_id;
       a.bp_count[x] = c.nleft | (c.nright << 16);
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
-      const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, c.qs, c.qn, ds, a.pg.nchars);
-      const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, c.qs, c.qn,
+      const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, c.qn, ds, a.pg.nchars);
+      const double d1 = dangle_energy_gapped(sc, h.q_sp + US(h.q_len) - 1, (int64_t)h.db_sp + US(h.db_len) - 1, 1, qs, c.qn,
                                              ds, a.pg.nchars);
-      double e = h.e_tot, hy = h.e_hyb;
+      double e = h.e_tot, hy = h.e_tot - h.e_acc; // (the hybridization energy as the last direction left it, :311)
       e += d0;
       e += d1;
       hy += d0;
@@ -891,7 +913,7 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
     int t = 0;
     const int64_t d0 = c.unsorted ? c.out0 : c.out0 + c.nleft;
     for (int u = 0; u < c.diag_len; u++)
-      if (diag_pairs(sc, c.qs[c.diag_q + u], ds[c.diag_d + u])) {
+      if (diag_pairs(sc, qs[c.diag_q + u], ds[c.diag_d + u])) {
         a.bp_out[2 * (d0 + t)] = c.diag_q + u;
         a.bp_out[2 * (d0 + t) + 1] = c.diag_d + u;
         t++;
@@ -942,18 +964,20 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
   int tick = 0; // iterations since the last boundary
   HitCtx c;
   DirState d;
+  const SeqBases sb{a.qb.enc, a.qb.acc, a.qb.cond, a.pg.acc, a.pg.cond};
   while (__ballot(phase != kDone) != 0) {
     GP_MARK(14);
     if (tick == 0) {
       if (phase == kFinished) {
         DirResult r{true, 0};
+        const DirOrigin og = dir_origin(c.h, flag);
         if (!d.overflow) {
-          r = dir_finish(d, c.h, flag); // (an overflowed direction leaves c.h as it was)
+          r = dir_finish(d, c.h, flag, S); // (an overflowed direction leaves c.h as it was)
         } else {
           if constexpr (kMode == 0 && T::kResumable)
             if (a.rout.slot) resume_dump<G, T, Rec>(a.rout, c, d, flag, lds[gid], gl, gbase);
         }
-        hit_dir_done<kMode, true>(a, c, flag, d, r, S, gl);
+        hit_dir_done<kMode, true>(a, c, flag, og, r, S, gl);
         group_sync<true>();
         GP_MARK(7);
         if (c.ovf || flag == 1) {
@@ -982,13 +1006,13 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
         GP_MARK(8);
       }
       if (phase == kInit) {
-        dir_init<G, true>(a.sc, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
+        dir_init<G, true>(a.sc, sb, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
         phase = kRun;
         GP_MARK(0);
       }
     }
     GP_MARK(15);
-    if (phase == kRun && dir_step<G, true>(a.sc, a.o, c, flag, S, gl, gbase, d, prof)) phase = kFinished;
+    if (phase == kRun && dir_step<G, true>(a.sc, sb, a.o, c, flag, S, gl, gbase, d, prof)) phase = kFinished;
     tick = tick + 1 == period ? 0 : tick + 1;
   }
   prof.flush(a.tier_id * 2 + (kMode != 0));
@@ -1012,18 +1036,20 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
   prof.start();
   HitCtx c;
   DirState d;
+  const SeqBases sb{a.qb.enc, a.qb.acc, a.qb.cond, a.pg.acc, a.pg.cond};
   for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) {
     hit_load<kMode>(a, w, c);
     int last = 0;
     for (int flag = c.resumed ? 1 : 0; flag < 2 && !c.ovf; flag++) {
       GP_MARK(8);
-      dir_init<64, false>(a.sc, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
+      dir_init<64, false>(a.sc, sb, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
       GP_MARK(0);
-      while (!dir_step<64, false>(a.sc, a.o, c, flag, S, gl, 0, d, prof)) {
+      while (!dir_step<64, false>(a.sc, sb, a.o, c, flag, S, gl, 0, d, prof)) {
       }
       DirResult r{true, 0};
-      if (!d.overflow) r = dir_finish(d, c.h, flag);
-      hit_dir_done<kMode, false>(a, c, flag, d, r, S, gl);
+      const DirOrigin og = dir_origin(c.h, flag);
+      if (!d.overflow) r = dir_finish(d, c.h, flag, S);
+      hit_dir_done<kMode, false>(a, c, flag, og, r, S, gl);
       group_sync<false>();
       last = flag;
       GP_MARK(7);
@@ -1031,7 +1057,7 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
     hit_store<kMode>(a, w, c, last, gl);
     GP_MARK(9);
   }
-  prof.flush(3 * 2 + (kMode != 0));
+  prof.flush(kWaveTier * 2 + (kMode != 0));
 }
 
 } // namespace
@@ -1039,16 +1065,18 @@ template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs
 #ifdef PRB_GAP_PROFILE
 extern "C" int prb_debug_gap_profile(unsigned long long *out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gap_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gap_prof), sizeof(unsigned long long) * 160) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[128] = {};
+    unsigned long long z[160] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_gap_prof), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
 }
 #endif
 
-size_t gapped_resume_bytes(int tier) { return tier == 0 ? resume_bytes<Tier0, Rec32>() : resume_bytes<Tier1, Rec32>(); }
+size_t gapped_resume_bytes(int tier) {
+  return tier == 0 ? resume_bytes<Tier0, Rec32>() : tier == 1 ? resume_bytes<Tier1, Rec32>() : resume_bytes<Tier2, Rec32>();
+}
 
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
   size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 4) + 2 * ((size_t)cap_diag + 16);
@@ -1076,7 +1104,8 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
             trace,   bp_off, bp_out, next_work, rin,     rout};
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
-  return launch_tier<Tier2, Rec32W>(a, mode, s);
+  if (tier == 2) return launch_tier<Tier2, Rec32>(a, mode, s);
+  return launch_tier<Tier3, Rec32W>(a, mode, s);
 }
 
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
@@ -1084,7 +1113,7 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
                               const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, 3, first_flag, bp_count,
+  GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, kWaveTier, first_flag, bp_count,
             nullptr, bp_off, bp_out, nullptr, GapResume{nullptr, nullptr, nullptr, 0}, GapResume{nullptr, nullptr, nullptr, 0}};
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
   if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
@@ -1104,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_bp_expand(HitSoA in, int64_t n, const u
   if (w >= n) return;
   const int64_t x = subset[w];
   const int nleft = ntrace[x] & 0xFFFF, nright = (int)((uint32_t)ntrace[x] >> 16);
-  if (tier_of[x] >= 3 || nleft > kTraceCap || nright > kTraceCap) return;
+  if (tier_of[x] >= kWaveTier || nleft > kTraceCap || nright > kTraceCap) return;
   const int q_sp = in.q_sp[x], db_sp = in.db_sp[x], len = US(in.q_len[x]);
   const uint8_t *qs = qb.enc + qb.off[in.query[x]] + q_sp;
   const uint8_t *ds = pg.seqs + db_sp;

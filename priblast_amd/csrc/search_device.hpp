@@ -144,7 +144,7 @@ __device__ __forceinline__ double dangle_energy_gapped(const SearchConst &sc, in
 
 struct HitState {
   int q_sp, db_sp, q_len, db_len, id_start;
-  double e_tot, e_acc, e_hyb;
+  double e_tot, e_acc; // (hybridization energy = e_tot - e_acc)
 };
 
 } // namespace prb

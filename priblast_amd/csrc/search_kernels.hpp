@@ -168,6 +168,9 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
 // launch_bp_expand writes the base pairs of the final hits from them (hits of the wave kernel or
 // with longer chains are skipped: they are traced by a mode-2 pass).
 constexpr int kTraceCap = 32;
+// ids of the gapped kernels a hit can be completed by (tier_out): LDS tiers 0..3, then the
+// wavefront-per-hit kernel with its state in HBM scratch
+constexpr int kLdsTiers = 4, kWaveTier = 4;
 hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                             const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
                             const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);

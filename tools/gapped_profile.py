@@ -35,17 +35,18 @@ def main():
     qb = capi.QBatch(ctx, qs, db.repeat_flag)
     qb.accessibility(db.W, db.delta)
     L = capi.lib()
-    buf = (ctypes.c_ulonglong * 128)()
+    buf = (ctypes.c_ulonglong * 160)()
     L.prb_debug_gap_profile(buf, 1)
     ctx.reset_timers()
     hits, bp, counts = capi.search_page(ctx, qb, db, 0, capi.default_opts(), 3)
     L.prb_debug_gap_profile(buf, 1)
-    allv = np.array(buf[:], dtype=np.float64).reshape(8, 16)
+    allv = np.array(buf[:], dtype=np.float64).reshape(10, 16)
     print(f"hits: seed {counts[0]}, post-ungapped {counts[1]}, final {counts[2]}")
-    for s in ("gapped", "gapped_t1", "gapped_slow", "traceback", "traceback_slow"):
+    for s in ("gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow"):
         print(f"  {s}: {ctx.stage_ms(s)[0]:.1f} ms")
     total = allv[:, :10].sum() + allv[:, 14:16].sum()
-    names = {0: "tier 0 extend", 1: "tier 0 trace", 2: "tier 1 extend", 3: "tier 1 trace", 6: "wave extend", 7: "wave trace"}
+    names = {0: "tier 0 extend", 1: "tier 0 trace", 2: "tier 1 extend", 3: "tier 1 trace", 4: "tier 2 extend", 5: "tier 2 trace",
+             6: "tier 3 extend", 7: "tier 3 trace", 8: "wave extend", 9: "wave trace"}
     # NOTE: the accumulators live in lane 0 of each wavefront, so a region also collects the time
     # lane 0's group spends masked off while other groups of the wavefront are still busy
     # (e.g. "dir/hit epilogue" = waiting for the longest extension of the wavefront).
