@@ -312,6 +312,12 @@ int prb_search_const_upload(prb_ctx *ctx) {
   v.terminal_au = p.terminal_au;
   for (int a = 0; a < 5; a++)
     for (int c = 0; c < 5; c++) v.bp_pair[a * 5 + c] = (unsigned char)p.bp_pair[a][c];
+  v.pair_mask = v.wobble_mask = 0;
+  for (int a = 0; a < 5; a++)
+    for (int c = 0; c < 5; c++) {
+      if (p.bp_pair[a][c] != 0) v.pair_mask |= 1u << (a * 5 + c);
+      if (p.bp_pair[a][c] == 3 || p.bp_pair[a][c] == 4) v.wobble_mask |= 1u << (a * 5 + c);
+    }
   return PRB_OK;
 }
 

@@ -611,22 +611,23 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     const int i = i0 + gl, j = d.length - i;
     int type1 = 0;
     if (i <= i_hi) {
-      // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases.  Everything it can
-      // need for a minimum helix of up to 3 is fetched at once (one LDS round trip instead of four).
-      const int q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
+      // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases, without branches
+      // (every lane of the wavefront walks through it anyway): pairs and wobble pairs are bits of two
+      // 25-bit masks indexed by 5 * query base + database base; the pair type is looked up at the end.
+      // The cell needs min_helix - 1 further pairs ahead, the first of them not a second wobble, when
+      // its diagonal predecessor holds no type or a wobble one under a wobble pair.
+      const unsigned q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
       const int pt = S.ptab(d2, i - 1);
-      type1 = bp_type(sc, q0, d0);
-      if (flag == 1) type1 = rtype_of(type1);
-      if (type1 != 0 && (pt == 0 || (wobble(type1) && wobble(pt)))) {
-        for (int x = 1; x <= min_helix - 1; x++) {
-          int t = x == 1 ? bp_type(sc, q1, d1) : x == 2 ? bp_type(sc, q2, d2b) : bp_type(sc, S.qb(i + x), S.db(j + x));
-          if (flag == 1) t = rtype_of(t);
-          if (t == 0 || (x == 1 && wobble(type1) && wobble(t))) {
-            type1 = 0;
-            break;
-          }
-        }
-      }
+      const unsigned x0 = q0 * 5 + d0, x1 = q1 * 5 + d1, x2 = q2 * 5 + d2b;
+      const unsigned p0 = (sc.pair_mask >> x0) & 1, w0 = (sc.wobble_mask >> x0) & 1;
+      unsigned ahead = 1;
+      if (min_helix >= 2) ahead = ((sc.pair_mask >> x1) & 1) & ~(w0 & (sc.wobble_mask >> x1));
+      if (min_helix >= 3) ahead &= sc.pair_mask >> x2;
+      for (int x = 3; x <= min_helix - 1; x++) ahead &= sc.pair_mask >> ((unsigned)S.qb(i + x) * 5 + S.db(j + x));
+      const unsigned need = (unsigned)(pt == 0) | (w0 & (unsigned)wobble(pt));
+      int t = (int)((sc.bp_rows >> ((x0 * 3 - 15) & 63)) & 7); // row q0 - 1, column d0 (meaningless without a pair)
+      if (flag == 1) t = ((t - 1) ^ 1) + 1;                     // rtype
+      type1 = (p0 & (ahead | ~need) & 1) ? t : 0;
     }
     // the types of the chunk's cells as three bit planes: a lane reads any cell's type from them
     // without going through LDS

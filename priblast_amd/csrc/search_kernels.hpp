@@ -40,6 +40,7 @@ struct SearchConst {
   // BP_pair (energy_par.hpp:17-23) packed 3 bits per entry, row a (1..4) at bit 15*(a-1);
   // rtype (energy_par.hpp:26) is the involution ((t-1)^1)+1, checked on the host
   uint64_t bp_rows;
+  uint32_t pair_mask, wobble_mask; // bit 5 * a + b: bases a, b pair / form a wobble pair (types 3, 4)
   unsigned char bp_pair[25];
 };
 
