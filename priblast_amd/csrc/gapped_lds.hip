@@ -24,6 +24,7 @@
 // cell list is re-read for every filled cell; per-thread scratch in HBM made every access a
 // dependent HBM round trip (r01 baseline profile: 117 ns/hit; LDS form: 19 ns/hit).
 #include <algorithm>
+#include <type_traits>
 
 #include "search_device.hpp"
 #include "search_kernels.hpp"
@@ -144,7 +145,9 @@ template <class T, class Rec> struct LdsState {
   double eq[T::kCapD], ed[T::kCapD];
   double hyb[T::kCapR];
   typename Rec::word info[T::kCapR];
-  uint8_t ptab[3][T::kCapD + 4];
+  // Cell::type rows: a cell has i <= kCapD - 1; whole 8-byte words, so a row is reset with one store per lane
+  static constexpr int kPtabLen = (T::kCapD + 7) & ~7;
+  alignas(8) uint8_t ptab[3][kPtabLen];
   uint8_t qb[T::kCapD + 16], db[T::kCapD + 16]; // bases along the extension, 0 = end of sequence / masked
 };
 template <class T, class Rec> struct LdsStore {
@@ -158,7 +161,7 @@ template <class T, class Rec> struct LdsStore {
   __device__ __forceinline__ double &hyb(int r) const { return s.hyb[r]; }
   __device__ __forceinline__ typename Rec::word &info(int r) const { return s.info[r]; }
   __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return s.ptab[row][i]; }
-  __device__ __forceinline__ int ptab_len() const { return T::kCapD + 4; } // indices 0..kCapD, a multiple of 4
+  __device__ __forceinline__ int ptab_len() const { return LdsState<T, Rec>::kPtabLen; }
   __device__ __forceinline__ int win_len() const { return T::kCapD + 16; }
   __device__ __forceinline__ uint8_t &qb(int t) const { return s.qb[t]; }
   __device__ __forceinline__ uint8_t &db(int t) const { return s.db[t]; }
@@ -515,14 +518,21 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
   // max_q_extension / max_db_extension as the reference has them after its checks at this d.length
   const bool q_open = d.length < d.tq0, d_open = d.length < d.td0;
   const int max_q = q_open ? 100000 : d.tq0 - 1, max_d = d_open ? 100000 : d.td0 - 1;
-  const int cur = d.length % 3, d2 = (d.length + 1) % 3; // d2 = (d.length - 2) mod 3
+  // d.length mod 3 (multiply-shift while the lengths are small) and (d.length - 2) mod 3
+  const int cur = kLds ? d.length - 3 * ((d.length * 171) >> 9) : d.length % 3, d2 = cur == 2 ? 0 : cur + 1;
+  static_assert(!kLds || Tier3::kCapD + 16 < 256, "multiply-shift division by 3");
   if (!mid) {
     // cumulative accessibility change beyond the lengths prepared so far (one direction in ten gets here)
     if (d.length > d.staged) stage_acc_regs<G, kLds>(sb, c, flag, delta, S, gl, gbase, d, d.length);
     GP_MARK(1);
     GP_COUNT(10);
     // recycle the row of anti-diagonal d.length-3 for this one
-    for (int t = gl; t <= d.length; t += G) S.ptab(cur, t) = 0;
+    if constexpr (kLds) {
+      uint64_t *row = reinterpret_cast<uint64_t *>(&S.ptab(cur, 0));
+      for (int t = gl; t < S.ptab_len() / 8; t += G) row[t] = 0;
+    } else {
+      for (int t = gl; t <= d.length; t += G) S.ptab(cur, t) = 0;
+    }
     group_sync<kLds>();
     // prune candidates with d.length - first - second - 2 > drop (:213-217): a prefix of the list
     if (d.length - 2 > drop) {
@@ -632,18 +642,20 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     // the types of the chunk's cells as three bit planes: a lane reads any cell's type from them
     // without going through LDS
     const unsigned long long tb0 = __ballot(type1 & 1), tb1 = __ballot(type1 & 2), tb2 = __ballot(type1 & 4);
-    unsigned long long vmask = tb0 | tb1 | tb2;
-    if (G < 64) vmask = (vmask >> gbase) & ((1ull << (G & 63)) - 1);
+    // (the group's own cells; 32-bit arithmetic where a group is at most half a wavefront)
+    using mask_t = typename std::conditional<G <= 32, uint32_t, unsigned long long>::type;
+    const unsigned long long anyb = tb0 | tb1 | tb2;
+    mask_t vmask = G < 64 ? (mask_t)((anyb >> gbase) & ((1ull << (G & 63)) - 1)) : (mask_t)anyb;
     GP_MARK(3);
     GP_COUNT(11);
-    if (Store::kResumable && d.nrec + __popcll(vmask) > S.cap_r()) { // out of cells: stop in front of this chunk
+    if (Store::kResumable && d.nrec + __popcll((unsigned long long)vmask) > S.cap_r()) { // out of cells: stop in front of this chunk
       d.overflow = true;
       d.resume_i0 = i0;
       d.resume_dstart = dstart;
       break;
     }
     while (vmask) { // filled cells of this chunk, ascending i
-      const int b = __builtin_ctzll(vmask);
+      const int b = G <= 32 ? __builtin_ctz((uint32_t)vmask) : __builtin_ctzll((unsigned long long)vmask);
       vmask &= vmask - 1;
       const int ci = i0 + b;
       const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
@@ -771,8 +783,9 @@ __device__ __forceinline__ void resume_load(const GapResume &ri, int slot, const
     const auto v = s0->info[t];
     S.info(t) = R::pack(RecS::i(v), RecS::j(v), RecS::pred(v), RecS::type(v), RecS::qa(v), RecS::da(v));
   }
-  for (int t = gl; t < 3 * (TS::kCapD + 4); t += G) {
-    const int row = t / (TS::kCapD + 4), i = t - row * (TS::kCapD + 4);
+  constexpr int kLenS = LdsState<TS, RecS>::kPtabLen;
+  for (int t = gl; t < 3 * kLenS; t += G) {
+    const int row = t / kLenS, i = t - row * kLenS;
     S.ptab(row, i) = s0->ptab[row][i];
   }
   group_sync<true>();
