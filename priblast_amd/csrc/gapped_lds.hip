@@ -515,9 +515,9 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     }
     d.length++;
   }
-  // max_q_extension / max_db_extension as the reference has them after its checks at this d.length
+  // max_q_extension / max_db_extension as the reference has them after its checks at this d.length:
+  // unbounded while the strand goes on, else the last position with a base
   const bool q_open = d.length < d.tq0, d_open = d.length < d.td0;
-  const int max_q = q_open ? 100000 : d.tq0 - 1, max_d = d_open ? 100000 : d.td0 - 1;
   // d.length mod 3 (multiply-shift while the lengths are small) and (d.length - 2) mod 3
   const int cur = kLds ? d.length - 3 * ((d.length * 171) >> 9) : d.length % 3, d2 = cur == 2 ? 0 : cur + 1;
   static_assert(!kLds || Tier3::kCapD + 16 < 256, "multiply-shift division by 3");
@@ -545,8 +545,10 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
   }
   GP_MARK(2);
   const int dstart = mid ? d.resume_dstart : d.nrec;
-  const int i_lo = mid ? d.resume_i0 : (d.length - max_d > 1 ? d.length - max_d : 1);
-  const int i_hi = max_q < d.length - 1 ? max_q : d.length - 1;
+  // cells 1 <= i <= d.length - 1 with i <= max_q and d.length - i <= max_d
+  const int i_first = d.length - d.td0 + 1 > 1 ? d.length - d.td0 + 1 : 1;
+  const int i_lo = mid ? d.resume_i0 : i_first;
+  const int i_hi = (d.length < d.tq0 ? d.length : d.tq0) - 1;
   d.resume_i0 = 0;
 
   // One filled cell (ci, d.length - ci) of pair type ctype: its best predecessor among the live
