@@ -551,6 +551,14 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
   const int i_hi = (d.length < d.tq0 ? d.length : d.tq0) - 1;
   d.resume_i0 = 0;
 
+  // the first G live candidates, for the first scan round of every filled cell of this anti-diagonal
+  typename R::word v_first = 0;
+  double h_first = 0;
+  if (d.lo + gl < dstart) {
+    v_first = S.info(d.lo + gl);
+    h_first = S.hyb(d.lo + gl);
+  }
+
   // One filled cell (ci, d.length - ci) of pair type ctype: its best predecessor among the live
   // candidates [d.lo, dstart), the new record, the running minimum.  Returns the predecessor's type
   // (what the reference stores as Cell::type), or -1 when the cell list is full.
@@ -563,13 +571,10 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     const int fq = S.qb(ci + 1), fd = S.db(cj + 1);        // likewise: the new record's far-side bases
     double bte = 1000000.0;                                // INF
     int bkp = d.lo << 3; // candidate index << 3 | its type (0: none looked at), so the type comes out of the reduction
-    // (the records of the next round are fetched while this round's energies are looked up)
-    typename R::word vn = 0;
-    double hn = 0;
-    if (d.lo + gl < dstart) {
-      vn = S.info(d.lo + gl);
-      hn = S.hyb(d.lo + gl);
-    }
+    // (the records of the next round are fetched while this round's energies are looked up; those of
+    // the first round are the same for every cell of the anti-diagonal and were fetched at its start)
+    typename R::word vn = v_first;
+    double hn = h_first;
     for (int k0 = d.lo; k0 < dstart; k0 += G) {
       GP_COUNT(13);
       const int k = k0 + gl;
