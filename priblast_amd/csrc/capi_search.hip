@@ -982,7 +982,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // state dumps for the hits that outgrow tier 0 (~15 %: room for one hit in four, at most 4 M), tier 1
   // (~4 %: one in eight, at most 2 M) and tier 2 (~0.7 %: one in 32, at most 1 M); rs[t] = dumps of tier t
   const GapResume no_resume{nullptr, nullptr, nullptr, 0};
-  GapResume rs[3] = {no_resume, no_resume, no_resume};
+  GapResume rs[kLdsTiers - 1] = {no_resume, no_resume, no_resume};
+  static_assert(kLdsTiers == 4, "one pool of state dumps per LDS tier but the last");
   if (!getenv("PRB_GAPPED_NO_RESUME")) {
     rs[0].cap = (int32_t)std::min<int64_t>(nung / 4 + 1024, 4 << 20);
     rs[1].cap = (int32_t)std::min<int64_t>(nung / 8 + 1024, 2 << 20);
@@ -1018,7 +1019,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                   w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
                                   w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,
-                                  tier <= 2 ? rs[tier] : no_resume, ctx->stream));
+                                  tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
         cur = bufs[nb];
