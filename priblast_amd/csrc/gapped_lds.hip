@@ -590,9 +590,12 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
           // LoopEnergy between the new pair and candidate k (:230-247); the loop lies between
           // offsets (ri, rj) and (ci, cj) from the start
           const int rq = R::kBases ? R::qa(v) : (int)S.qb(ri + 1), rd = R::kBases ? R::da(v) : (int)S.db(rj + 1);
-          double te;
-          if (flag == 0) te = loop_energy_abcd(sc, ctype, R::type(v), ci - ri - 1, cj - rj - 1, nq, nd, rq, rd);
-          else te = loop_energy_abcd(sc, R::type(v), ctype, ci - ri - 1, cj - rj - 1, rq, rd, nq, nd);
+          // (the groups of a wavefront are in different directions most of the time: the outer and the
+          // inner pair are put in place with selects, so there is one copy of the look-up, not one per direction)
+          const bool f0 = flag == 0;
+          const int rt = R::type(v);
+          double te = loop_energy_abcd(sc, f0 ? ctype : rt, f0 ? rt : ctype, ci - ri - 1, cj - rj - 1, f0 ? nq : rq, f0 ? nd : rd,
+                                       f0 ? rq : nq, f0 ? rd : nd);
           te += hk;
           if (te < bte) {
             bte = te;
