@@ -331,33 +331,21 @@ __device__ __forceinline__ void stage_acc(const SeqBases &sb, const HitCtx &c, i
     group_sync<kLds>();
   }
   auto get = [&](int k, int t) -> float { return scratch ? scratch[k * nb + t] : term(k, L0 + t); };
-  if (gl == 0) {
-    for (int k = 0; k < nb && L0 + k < d.tq0 && L0 + k <= S.cap_d(); k++) {
+  // The two chains run side by side on lanes 0 and 1, in one instruction stream whatever the direction
+  // (the groups of a wavefront are in different directions most of the time): the side the extension
+  // runs along the accessible region of has three terms per length, the other one.
+  if (gl < 2) {
+    const bool qside = gl == 0, three = qside == (flag == 0);
+    const int kb = qside ? 0 : 3, lim = qside ? d.tq0 : d.td0;
+    double *out = qside ? &S.eq(0) : &S.ed(0);
+    for (int k = 0; k < nb && L0 + k < lim && L0 + k <= S.cap_d(); k++) {
       const int len = L0 + k;
+      const float x = get(kb, k), y = get(kb + 1, k), z = get(kb + 2, k); // (y, z: whatever the scratch holds on the one-term side)
       double v;
-      if (flag == 0) {
-        if (len == 1) v = get(0, k) - get(1, k) + get(2, k); // float arithmetic, as the reference
-        else v = d.acc_prev + get(0, k) - get(1, k) + get(2, k);
-      } else {
-        if (len == 1) v = get(0, k);
-        else v = d.acc_prev + get(0, k);
-      }
+      if (len == 1) v = three ? (double)(x - y + z) : (double)x; // float arithmetic, as the reference
+      else v = three ? d.acc_prev + x - y + z : d.acc_prev + x;
       d.acc_prev = v;
-      S.eq(len - 1) = v;
-    }
-  } else if (gl == 1) {
-    for (int k = 0; k < nb && L0 + k < d.td0 && L0 + k <= S.cap_d(); k++) {
-      const int len = L0 + k;
-      double v;
-      if (flag == 0) {
-        if (len == 1) v = get(3, k);
-        else v = d.acc_prev + get(3, k);
-      } else {
-        if (len == 1) v = get(3, k) - get(4, k) + get(5, k);
-        else v = d.acc_prev + get(3, k) - get(4, k) + get(5, k);
-      }
-      d.acc_prev = v;
-      S.ed(len - 1) = v;
+      out[len - 1] = v;
     }
   }
   d.staged = L0 + nb - 1 < S.cap_d() ? L0 + nb - 1 : S.cap_d();
