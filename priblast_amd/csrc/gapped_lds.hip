@@ -643,13 +643,25 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
       if (flag == 1) t = ((t - 1) ^ 1) + 1;                     // rtype
       type1 = (p0 & (ahead | ~need) & 1) ? t : 0;
     }
-    // the types of the chunk's cells as three bit planes: a lane reads any cell's type from them
-    // without going through LDS
-    const unsigned long long tb0 = __ballot(type1 & 1), tb1 = __ballot(type1 & 2), tb2 = __ballot(type1 & 4);
-    // (the group's own cells; 32-bit arithmetic where a group is at most half a wavefront)
+    // which cells of the chunk are filled (the group's share of a ballot; 32-bit arithmetic where a
+    // group is at most half a wavefront), and their types where every lane of the group can read them
+    // without going through LDS: eight lanes pack them into one word (3 bits per cell, an OR butterfly
+    // over DPP), larger groups keep them as three ballots
     using mask_t = typename std::conditional<G <= 32, uint32_t, unsigned long long>::type;
-    const unsigned long long anyb = tb0 | tb1 | tb2;
-    mask_t vmask = G < 64 ? (mask_t)((anyb >> gbase) & ((1ull << (G & 63)) - 1)) : (mask_t)anyb;
+    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
+    uint32_t types8 = 0;
+    mask_t vmask;
+    if constexpr (G == 8) {
+      types8 = (uint32_t)type1 << (3 * gl);
+      types8 |= (uint32_t)dpp_i32<0xB1>((int)types8);
+      types8 |= (uint32_t)dpp_i32<0x4E>((int)types8);
+      types8 |= (uint32_t)dpp_i32<0x141>((int)types8);
+      vmask = (mask_t)((__ballot(type1 != 0) >> gbase) & 0xFF);
+    } else {
+      tb0 = __ballot(type1 & 1), tb1 = __ballot(type1 & 2), tb2 = __ballot(type1 & 4);
+      const unsigned long long anyb = tb0 | tb1 | tb2;
+      vmask = G < 64 ? (mask_t)((anyb >> gbase) & ((1ull << (G & 63)) - 1)) : (mask_t)anyb;
+    }
     GP_MARK(3);
     GP_COUNT(11);
     if (Store::kResumable && d.nrec + __popcll((unsigned long long)vmask) > S.cap_r()) { // out of cells: stop in front of this chunk
@@ -662,8 +674,9 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
       const int b = G <= 32 ? __builtin_ctz((uint32_t)vmask) : __builtin_ctzll((unsigned long long)vmask);
       vmask &= vmask - 1;
       const int ci = i0 + b;
-      const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
-                        (int)(((tb2 >> (gbase + b)) & 1) << 2);
+      const int ctype = G == 8 ? (int)((types8 >> (3 * b)) & 7)
+                               : (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
+                                     (int)(((tb2 >> (gbase + b)) & 1) << 2);
       const int ptype = fill_cell(ci, ctype);
       if (ptype < 0) {
         d.overflow = true;
