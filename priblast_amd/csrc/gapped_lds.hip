@@ -153,6 +153,7 @@ template <class T, class Rec> struct LdsState {
 template <class T, class Rec> struct LdsStore {
   using R = Rec;
   static constexpr bool kResumable = T::kResumable;
+  static constexpr int kCapD = T::kCapD;
   LdsState<T, Rec> &s;
   __device__ __forceinline__ int cap_d() const { return T::kCapD; }
   __device__ __forceinline__ int cap_r() const { return T::kCapR; }
@@ -621,63 +622,68 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     return ptype;
   };
 
-  for (int i0 = i_lo; i0 <= i_hi && !d.overflow; i0 += G) {
-    const int i = i0 + gl, j = d.length - i;
-    int type1 = 0;
-    if (i <= i_hi) {
-      // CheckHelixLength (:342-364) with GetBPType (:321-338) on the staged bases, without branches
-      // (every lane of the wavefront walks through it anyway): pairs and wobble pairs are bits of two
-      // 25-bit masks indexed by 5 * query base + database base; the pair type is looked up at the end.
-      // The cell needs min_helix - 1 further pairs ahead, the first of them not a second wobble, when
-      // its diagonal predecessor holds no type or a wobble one under a wobble pair.
-      const unsigned q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
-      const int pt = S.ptab(d2, i - 1);
-      const unsigned x0 = q0 * 5 + d0, x1 = q1 * 5 + d1, x2 = q2 * 5 + d2b;
-      const unsigned p0 = (sc.pair_mask >> x0) & 1, w0 = (sc.wobble_mask >> x0) & 1;
-      unsigned ahead = 1;
-      if (min_helix >= 2) ahead = ((sc.pair_mask >> x1) & 1) & ~(w0 & (sc.wobble_mask >> x1));
-      if (min_helix >= 3) ahead &= sc.pair_mask >> x2;
-      for (int x = 3; x <= min_helix - 1; x++) ahead &= sc.pair_mask >> ((unsigned)S.qb(i + x) * 5 + S.db(j + x));
-      const unsigned need = (unsigned)(pt == 0) | (w0 & (unsigned)wobble(pt));
-      int t = (int)((sc.bp_rows >> ((x0 * 3 - 15) & 63)) & 7); // row q0 - 1, column d0 (meaningless without a pair)
-      if (flag == 1) t = ((t - 1) ^ 1) + 1;                     // rtype
-      type1 = (p0 & (ahead | ~need) & 1) ? t : 0;
-    }
-    // which cells of the chunk are filled (the group's share of a ballot; 32-bit arithmetic where a
-    // group is at most half a wavefront), and their types where every lane of the group can read them
-    // without going through LDS: eight lanes pack them into one word (3 bits per cell, an OR butterfly
-    // over DPP), larger groups keep them as three ballots
-    using mask_t = typename std::conditional<G <= 32, uint32_t, unsigned long long>::type;
-    unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
-    uint32_t types8 = 0;
-    mask_t vmask;
-    if constexpr (G == 8) {
-      types8 = (uint32_t)type1 << (3 * gl);
-      types8 |= (uint32_t)dpp_i32<0xB1>((int)types8);
-      types8 |= (uint32_t)dpp_i32<0x4E>((int)types8);
-      types8 |= (uint32_t)dpp_i32<0x141>((int)types8);
-      vmask = (mask_t)((__ballot(type1 != 0) >> gbase) & 0xFF);
-    } else {
-      tb0 = __ballot(type1 & 1), tb1 = __ballot(type1 & 2), tb2 = __ballot(type1 & 4);
-      const unsigned long long anyb = tb0 | tb1 | tb2;
-      vmask = G < 64 ? (mask_t)((anyb >> gbase) & ((1ull << (G & 63)) - 1)) : (mask_t)anyb;
+  // CheckHelixLength (:342-364) with GetBPType (:321-338) for cell (i, d.length - i) on the staged
+  // bases, without branches (every lane of the wavefront walks through it anyway): pairs and wobble
+  // pairs are bits of two 25-bit masks indexed by 5 * query base + database base; the pair type is
+  // looked up at the end.  The cell needs min_helix - 1 further pairs ahead, the first of them not a
+  // second wobble, when its diagonal predecessor holds no type or a wobble one under a wobble pair.
+  auto cell_type = [&](int i) -> int {
+    if (i > i_hi) return 0;
+    const int j = d.length - i;
+    const unsigned q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
+    const int pt = S.ptab(d2, i - 1);
+    const unsigned x0 = q0 * 5 + d0, x1 = q1 * 5 + d1, x2 = q2 * 5 + d2b;
+    const unsigned p0 = (sc.pair_mask >> x0) & 1, w0 = (sc.wobble_mask >> x0) & 1;
+    unsigned ahead = 1;
+    if (min_helix >= 2) ahead = ((sc.pair_mask >> x1) & 1) & ~(w0 & (sc.wobble_mask >> x1));
+    if (min_helix >= 3) ahead &= sc.pair_mask >> x2;
+    for (int x = 3; x <= min_helix - 1; x++) ahead &= sc.pair_mask >> ((unsigned)S.qb(i + x) * 5 + S.db(j + x));
+    const unsigned need = (unsigned)(pt == 0) | (w0 & (unsigned)wobble(pt));
+    int t = (int)((sc.bp_rows >> ((x0 * 3 - 15) & 63)) & 7); // row q0 - 1, column d0 (meaningless without a pair)
+    if (flag == 1) t = ((t - 1) ^ 1) + 1;                     // rtype
+    return (p0 & (ahead | ~need) & 1) ? t : 0;
+  };
+
+  if constexpr (G == 8 && kLds) {
+    // Eight-lane groups: all chunks of the anti-diagonal are checked first and its filled cells handled
+    // in ONE loop, so a wavefront runs as many fill iterations as its busiest group has cells on the
+    // anti-diagonal - not, chunk after chunk, as many as the busiest group of that chunk.  The types of
+    // a chunk's cells are packed into one word (3 bits per cell, an OR butterfly over DPP): every lane
+    // of the group reads any cell's type without going through LDS.
+    constexpr int kChunks = (Store::kCapD + G - 1) / G;
+    using cells_t = typename std::conditional<kChunks <= 4, uint32_t, unsigned long long>::type;
+    uint32_t tw[kChunks];
+    cells_t cells = 0;
+#pragma unroll
+    for (int c = 0; c < kChunks; c++) {
+      tw[c] = 0;
+      const int i0 = i_lo + c * G;
+      if (i0 <= i_hi) {
+        const int type1 = cell_type(i0 + gl);
+        uint32_t w = (uint32_t)type1 << (3 * gl);
+        w |= (uint32_t)dpp_i32<0xB1>((int)w);
+        w |= (uint32_t)dpp_i32<0x4E>((int)w);
+        w |= (uint32_t)dpp_i32<0x141>((int)w);
+        tw[c] = w;
+        cells |= (cells_t)((__ballot(type1 != 0) >> gbase) & 0xFF) << (8 * c);
+        GP_COUNT(11);
+      }
     }
     GP_MARK(3);
-    GP_COUNT(11);
-    if (Store::kResumable && d.nrec + __popcll((unsigned long long)vmask) > S.cap_r()) { // out of cells: stop in front of this chunk
-      d.overflow = true;
-      d.resume_i0 = i0;
-      d.resume_dstart = dstart;
-      break;
-    }
-    while (vmask) { // filled cells of this chunk, ascending i
-      const int b = G <= 32 ? __builtin_ctz((uint32_t)vmask) : __builtin_ctzll((unsigned long long)vmask);
-      vmask &= vmask - 1;
-      const int ci = i0 + b;
-      const int ctype = G == 8 ? (int)((types8 >> (3 * b)) & 7)
-                               : (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
-                                     (int)(((tb2 >> (gbase + b)) & 1) << 2);
-      const int ptype = fill_cell(ci, ctype);
+    while (cells) { // filled cells of the anti-diagonal, ascending i
+      const int b = kChunks <= 4 ? __builtin_ctz((uint32_t)cells) : __builtin_ctzll((unsigned long long)cells);
+      const int ci = i_lo + b;
+      if (Store::kResumable && d.nrec >= S.cap_r()) { // out of cells: stop in front of this one
+        d.overflow = true;
+        d.resume_i0 = ci;
+        d.resume_dstart = dstart;
+        break;
+      }
+      cells &= cells - 1;
+      uint32_t w = tw[0];
+#pragma unroll
+      for (int c = 1; c < kChunks; c++) w = (b >> 3) == c ? tw[c] : w;
+      const int ptype = fill_cell(ci, (int)((w >> (3 * (b & 7))) & 7));
       if (ptype < 0) {
         d.overflow = true;
         break;
@@ -686,6 +692,38 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     }
     group_sync<kLds>();
     GP_MARK(3);
+  } else {
+    for (int i0 = i_lo; i0 <= i_hi && !d.overflow; i0 += G) {
+      const int type1 = cell_type(i0 + gl);
+      // which cells of the chunk are filled (the group's share of a ballot), and their types as three
+      // bit planes: a lane reads any cell's type from them without going through LDS
+      using mask_t = typename std::conditional<G <= 32, uint32_t, unsigned long long>::type;
+      const unsigned long long tb0 = __ballot(type1 & 1), tb1 = __ballot(type1 & 2), tb2 = __ballot(type1 & 4);
+      const unsigned long long anyb = tb0 | tb1 | tb2;
+      mask_t vmask = G < 64 ? (mask_t)((anyb >> gbase) & ((1ull << (G & 63)) - 1)) : (mask_t)anyb;
+      GP_MARK(3);
+      GP_COUNT(11);
+      if (Store::kResumable && d.nrec + __popcll((unsigned long long)vmask) > S.cap_r()) { // out of cells: stop in front of this chunk
+        d.overflow = true;
+        d.resume_i0 = i0;
+        d.resume_dstart = dstart;
+        break;
+      }
+      while (vmask) { // filled cells of this chunk, ascending i
+        const int b = G <= 32 ? __builtin_ctz((uint32_t)vmask) : __builtin_ctzll((unsigned long long)vmask);
+        vmask &= vmask - 1;
+        const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
+                          (int)(((tb2 >> (gbase + b)) & 1) << 2);
+        const int ptype = fill_cell(i0 + b, ctype);
+        if (ptype < 0) {
+          d.overflow = true;
+          break;
+        }
+        if (gl == 0) S.ptab(cur, i0 + b) = (uint8_t)ptype;
+      }
+      group_sync<kLds>();
+      GP_MARK(3);
+    }
   }
   if (d.overflow) return true;
   if (d.length - (d.min_ci + d.min_cj) >= drop) return true;
