@@ -214,6 +214,21 @@ template <int kCtrl> __device__ __forceinline__ double dpp_f64(double x) {
   return __hiloint2double(hi, lo);
 }
 template <int kCtrl> __device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(0, x, kCtrl, 0xF, 0xF, false); }
+// The same for an eight-lane group that may be working as two halves of four (two cells at once):
+// `halves` stops the reduction at the quads.
+__device__ __forceinline__ void group_min_halves(double &te, int &key, bool halves) {
+  double m = te;
+  m = __builtin_fmin(m, dpp_f64<0xB1>(m)); // quad_perm [1,0,3,2]
+  m = __builtin_fmin(m, dpp_f64<0x4E>(m)); // quad_perm [2,3,0,1]
+  const double m8 = __builtin_fmin(m, dpp_f64<0x141>(m)); // row_half_mirror: lane i <-> 7 - i
+  m = halves ? m : m8;
+  int k = te == m ? key : 0x7fffffff;
+  k = min(k, dpp_i32<0xB1>(k));
+  k = min(k, dpp_i32<0x4E>(k));
+  const int k8 = min(k, dpp_i32<0x141>(k));
+  te = m;
+  key = halves ? k : k8;
+}
 template <int G> __device__ __forceinline__ void group_min(double &te, int &key) {
   if (G == 8 || G == 16) {
     double m = te;
@@ -557,27 +572,45 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
   // One filled cell (ci, d.length - ci) of pair type ctype: its best predecessor among the live
   // candidates [d.lo, dstart), the new record, the running minimum.  Returns the predecessor's type
   // (what the reference stores as Cell::type), or -1 when the cell list is full.
-  auto fill_cell = [&](int ci, int ctype) -> int {
+  // `two` (eight-lane groups only): the group handles TWO cells of the anti-diagonal at once, lanes 0-3
+  // the first (ci, ctype as those lanes see them), lanes 4-7 the next one: the eight groups of a
+  // wavefront run this in lockstep, so what counts is the number of iterations of the busiest group.
+  // Cells of one anti-diagonal never see each other, their records go into the list in cell order, and
+  // the running minimum is updated first cell first (strict '<'), as if they had come one by one.
+  constexpr bool kTwoCells = G == 8 && kLds;
+  auto fill_cell = [&](int ci, int ctype, bool two) -> int {
     GP_COUNT(12);
+    const bool pair_mode = kTwoCells && two, hi = pair_mode && gl >= G / 2;
+    const int sub = pair_mode ? (gl & (G / 2 - 1)) : gl, stride = pair_mode ? G / 2 : G;
     const int cj = d.length - ci;
-    // scan the live candidates [d.lo, dstart), G per round; strict '<' keeps the first
+    // scan the live candidates [d.lo, dstart), `stride` per round; strict '<' keeps the first
     const int nq = S.qb(ci - 1), nd = S.db(cj - 1); // the bases next to the new pair on the loop side
     const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1); // needed after the scan; fetched behind it
     const int fq = S.qb(ci + 1), fd = S.db(cj + 1);        // likewise: the new record's far-side bases
     double bte = 1000000.0;                                // INF
     int bkp = d.lo << 3; // candidate index << 3 | its type (0: none looked at), so the type comes out of the reduction
     // (the records of the next round are fetched while this round's energies are looked up; those of
-    // the first round are the same for every cell of the anti-diagonal and were fetched at its start)
+    // the first round are the same for every cell of the anti-diagonal and were fetched at its start -
+    // with two cells, lanes 4-7 take theirs from lanes 0-3)
     typename R::word vn = v_first;
     double hn = h_first;
-    for (int k0 = d.lo; k0 < dstart; k0 += G) {
+    if constexpr (kTwoCells) {
+      if (pair_mode) {
+        const typename R::word v4 = (typename R::word)dpp_i32<0x114>((int)v_first); // row_shr:4
+        const double h4 = dpp_f64<0x114>(h_first);
+        vn = hi ? v4 : v_first;
+        hn = hi ? h4 : h_first;
+        if (sub + d.lo >= dstart) vn = 0; // (what the owner of this slot would hold)
+      }
+    }
+    for (int k0 = d.lo; k0 < dstart; k0 += stride) {
       GP_COUNT(13);
-      const int k = k0 + gl;
+      const int k = k0 + sub;
       const auto v = vn;
       const double hk = hn;
-      if (k + G < dstart) {
-        vn = S.info(k + G);
-        hn = S.hyb(k + G);
+      if (k + stride < dstart) {
+        vn = S.info(k + stride);
+        hn = S.hyb(k + stride);
       }
       if (k < dstart) {
         const int ri = R::i(v), rj = R::j(v);
@@ -600,24 +633,49 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
       }
     }
     GP_MARK(4);
-    group_min<G>(bte, bkp); // "first candidate in list order wins under strict <"
+    if constexpr (kTwoCells) group_min_halves(bte, bkp, pair_mode);
+    else group_min<G>(bte, bkp); // "first candidate in list order wins under strict <"
     GP_MARK(5);
-    if (d.nrec >= S.cap_r()) return -1;
+    if (d.nrec >= S.cap_r()) return -1; // (never with two cells: the caller made sure of room for both)
     int bk = bkp >> 3, ptype = bkp & 7;
     if (d.lo >= dstart) bk = 0;                  // empty window: the reference reads stem_candidate[0] of an empty list
     if (ptype == 0) ptype = R::type(S.info(bk)); // no candidate qualified: the type of that default entry
-    if (gl == 0) {
-      S.hyb(d.nrec) = bte;
-      S.info(d.nrec) = R::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
+    const int rec = d.nrec + (hi ? 1 : 0);
+    if (sub == 0) {
+      S.hyb(rec) = bte;
+      S.info(rec) = R::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
+      S.ptab(cur, ci) = (uint8_t)ptype;
     }
     const double ie = eq_c + ed_c + bte;
-    if (ie < d.min_e) { // (:260-278; everything else the reference notes down here follows from the cell)
-      d.min_e = ie;
-      d.best = d.nrec;
-      d.min_ci = ci;
-      d.min_cj = cj;
+    if constexpr (kTwoCells) {
+      // the first cell (lanes 0-3), then the second (lanes 4-7): each half gets the other's values
+      // from its mirror lane
+      const double ie_o = dpp_f64<0x141>(ie);
+      const int ci_o = dpp_i32<0x141>(ci);
+      const double ie_a = hi ? ie_o : ie, ie_b = hi ? ie : ie_o;
+      const int ci_a = hi ? ci_o : ci, ci_b = hi ? ci : ci_o;
+      if (ie_a < d.min_e) { // (:260-278; everything else the reference notes down here follows from the cell)
+        d.min_e = ie_a;
+        d.best = d.nrec;
+        d.min_ci = ci_a;
+        d.min_cj = d.length - ci_a;
+      }
+      if (pair_mode && ie_b < d.min_e) {
+        d.min_e = ie_b;
+        d.best = d.nrec + 1;
+        d.min_ci = ci_b;
+        d.min_cj = d.length - ci_b;
+      }
+      d.nrec += pair_mode ? 2 : 1;
+    } else {
+      if (ie < d.min_e) { // (:260-278; everything else the reference notes down here follows from the cell)
+        d.min_e = ie;
+        d.best = d.nrec;
+        d.min_ci = ci;
+        d.min_cj = cj;
+      }
+      d.nrec++;
     }
-    d.nrec++;
     GP_MARK(6);
     return ptype;
   };
@@ -670,25 +728,32 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
       }
     }
     GP_MARK(3);
-    while (cells) { // filled cells of the anti-diagonal, ascending i
-      const int b = kChunks <= 4 ? __builtin_ctz((uint32_t)cells) : __builtin_ctzll((unsigned long long)cells);
-      const int ci = i_lo + b;
+    while (cells) { // filled cells of the anti-diagonal, ascending i, two at a time where there are two
+      const cells_t rest = cells & (cells - 1);
+      const bool two = rest != 0 && d.nrec + 2 <= S.cap_r();
+      const int b0 = kChunks <= 4 ? __builtin_ctz((uint32_t)cells) : __builtin_ctzll((unsigned long long)cells);
       if (Store::kResumable && d.nrec >= S.cap_r()) { // out of cells: stop in front of this one
         d.overflow = true;
-        d.resume_i0 = ci;
+        d.resume_i0 = i_lo + b0;
         d.resume_dstart = dstart;
         break;
       }
-      cells &= cells - 1;
+      int b = b0;
+      if (two) {
+        const int b1 = kChunks <= 4 ? __builtin_ctz((uint32_t)rest) : __builtin_ctzll((unsigned long long)rest);
+        if (gl >= G / 2) b = b1;
+        cells = rest & (rest - 1);
+      } else {
+        cells = rest;
+      }
       uint32_t w = tw[0];
 #pragma unroll
       for (int c = 1; c < kChunks; c++) w = (b >> 3) == c ? tw[c] : w;
-      const int ptype = fill_cell(ci, (int)((w >> (3 * (b & 7))) & 7));
+      const int ptype = fill_cell(i_lo + b, (int)((w >> (3 * (b & 7))) & 7), two);
       if (ptype < 0) {
         d.overflow = true;
         break;
       }
-      if (gl == 0) S.ptab(cur, ci) = (uint8_t)ptype;
     }
     group_sync<kLds>();
     GP_MARK(3);
@@ -714,12 +779,11 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
         vmask &= vmask - 1;
         const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
                           (int)(((tb2 >> (gbase + b)) & 1) << 2);
-        const int ptype = fill_cell(i0 + b, ctype);
+        const int ptype = fill_cell(i0 + b, ctype, false);
         if (ptype < 0) {
           d.overflow = true;
           break;
         }
-        if (gl == 0) S.ptab(cur, i0 + b) = (uint8_t)ptype;
       }
       group_sync<kLds>();
       GP_MARK(3);
