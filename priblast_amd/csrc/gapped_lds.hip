@@ -12,12 +12,16 @@
 // cell are scanned G at a time and reduced with an order-preserving (energy, index) minimum,
 // i.e. "first candidate in list order wins under strict <"; the scalars of the recurrence are
 // kept redundantly in every lane.  The reference's growing 100x100 Cell matrix never exists.
+// The groups of a wavefront run all of this in lockstep, so a loop costs what its busiest group
+// needs: the kernels are shaped to keep that maximum small (one loop over the filled cells of an
+// anti-diagonal, two cells at once on half a group each, one instruction stream for both
+// directions) rather than to keep every lane busy.
 //
 // Two forms, a cascade of five kernels (a hit goes on to the next one when it outgrows the state a
 // kernel has room for; the LDS tiers hand their state over, so the next tier continues instead of
 // starting again):
 //   k_gapped_lds   state in LDS.  Tier 0: 8 lanes per hit, 30 anti-diagonals and 48 cells per
-//                  direction (1.26 KB per hit, 128 hits and 4 wavefronts per SIMD on a CU); tier 1:
+//                  direction (1.25 KB per hit, 128 hits and 4 wavefronts per SIMD on a CU); tier 1:
 //                  8 lanes, 40 / 64; tier 2: 16 lanes, 64 / 120; tier 3: a wavefront per hit, 128 / 512
 //   k_gapped_wave  G = 64, state in HBM scratch sized at run time: the rest
 // Why: an extension is small (median 16 anti-diagonals, ~10 filled cells per direction) but its
