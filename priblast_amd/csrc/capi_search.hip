@@ -908,12 +908,14 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // The cascade of kernels a hit goes through until one has the capacity for it: LDS tiers 0 and 1
   // (8 lanes per hit), tier 2 (16 lanes), tier 3 (a wavefront per hit), then the wave-per-hit kernel
   // with HBM scratch of any size.
-  // The environment switches exist for the tests: they force the rarely taken kernels.
-  std::vector<int> cascade{0, 1, 2, 3, kWaveTier};
-  if (getenv("PRB_FORCE_WAVE_GAPPED")) cascade = {kWaveTier};
-  else if (getenv("PRB_GAPPED_SKIP_TIER1")) cascade = {3, kWaveTier};
-  else if (getenv("PRB_GAPPED_SKIP_TIER0")) cascade = {2, kWaveTier};
-  else if (getenv("PRB_GAPPED_SKIP_SMALL")) cascade = {1, 2, 3, kWaveTier};
+  // PRB_GAPPED_FIRST_TIER exists for the tests: the cascade starts at that kernel (4 = the wave-per-hit
+  // kernel alone), so the rarely taken kernels see every hit, from scratch.
+  std::vector<int> cascade;
+  {
+    const char *e = getenv("PRB_GAPPED_FIRST_TIER");
+    const int first = e ? std::min(std::max(atoi(e), 0), kWaveTier) : 0;
+    for (int t = first; t <= kWaveTier; t++) cascade.push_back(t);
+  }
   auto scratch_for = [&](int64_t n, int cap_diag, int cap_rec, GapScratch &gs) -> int {
     gs.cap_diag = cap_diag;
     gs.cap_rec = cap_rec;

@@ -114,8 +114,8 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
                 assert f.read() == g.read(), (tag, ext)
 
 
-@pytest.mark.parametrize("env", ["PRB_FORCE_WAVE_GAPPED", "PRB_GAPPED_SKIP_TIER1", "PRB_GAPPED_SKIP_TIER0",
-                                 "PRB_GAPPED_SKIP_SMALL", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
+@pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
+                                 "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
                                  "PRB_GAPPED_NO_RESUME"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
@@ -125,6 +125,7 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     base pairs from the trace slots of the extension pass; likewise the general four-key sort
     instead of the one-key sort + tie pass."""
     from priblast_amd import capi
+    env, _, value = env.partition("=")
     for tag in ("c1", "mix"):
         names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
         db = capi.Db(ctx, os.path.join(golden_dir, f"{tag}db"))
@@ -134,7 +135,7 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
             for page in range(db.npages):
                 monkeypatch.delenv(env, raising=False)
                 h1, bp1, c1 = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
-                monkeypatch.setenv(env, "1")
+                monkeypatch.setenv(env, value or "1")
                 h2, bp2, c2 = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
                 assert c1 == c2
                 assert np.array_equal(h1, h2) and np.array_equal(bp1, bp2)
