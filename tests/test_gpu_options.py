@@ -32,6 +32,8 @@ OPTION_SETS = [
     dict(drop_out_w_gap=4, drop_out_wo_gap=2),
     dict(drop_out_w_gap=30, drop_out_wo_gap=12, min_helix_length=1),
     dict(min_helix_length=5, final_threshold=-6.0),
+    dict(min_helix_length=2),
+    dict(min_helix_length=9, interaction_threshold=-2.0, final_threshold=-4.0, drop_out_w_gap=24),
 ]
 ORACLE_NAMES = dict(max_seed_length="max_seed_length", hybrid_threshold="hybrid_thr", interaction_threshold="interaction_thr",
                     final_threshold="final_thr", drop_out_w_gap="drop_w_gap", drop_out_wo_gap="drop_wo_gap",
