@@ -67,12 +67,12 @@ struct PinnedBuf {
 
 // buffers reused across prb_search_page calls
 struct SearchWs {
-  DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
+  DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
       scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
-    for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
+    for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
                       &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount})
       b->release();
@@ -621,7 +621,7 @@ static int bits_for(int64_t max_value) {
   return b;
 }
 
-static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &in, HitSoA out, int64_t n, int nq, const SortBounds &sb,
+static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitRec *recs, HitSoA out, int64_t n, int nq, const SortBounds &sb,
                      uint32_t **perm_out) {
   int rc;
   const size_t N = (size_t)n;
@@ -638,7 +638,7 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &in, HitSoA out, in
       if ((rc = w.kP.ensure(N * 8)) || (rc = w.kTmp2.ensure(N * 8)) || (rc = w.kE.ensure(N * 8)) || (rc = w.kTmp.ensure(N * 8)) ||
           (rc = w.idxA.ensure(N * 4)) || (rc = w.idxB.ensure(N * 4)) || (rc = w.pending.ensure(16)))
         return rc;
-      PRB_HIP(launch_make_packed_keys(in, n, f, w.kP.as<uint64_t>(), w.kE.as<uint64_t>(), w.idxA.as<uint32_t>(), ctx->stream));
+      PRB_HIP(launch_make_packed_keys_recs(recs, n, f, w.kP.as<uint64_t>(), w.kE.as<uint64_t>(), w.idxA.as<uint32_t>(), ctx->stream));
       size_t tmp = 0;
       PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.idxA.as<uint32_t>(),
                                         w.idxB.as<uint32_t>(), N, 0, (unsigned)total, ctx->stream));
@@ -653,12 +653,16 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &in, HitSoA out, in
       PRB_HIP(hipMemcpyAsync(&too_long, w.pending.p, 4, hipMemcpyDeviceToHost, ctx->stream));
       PRB_HIP(hipStreamSynchronize(ctx->stream));
       if (!too_long) {
-        PRB_HIP(launch_gather_hits(in, w.idxB.as<uint32_t>(), out, n, ctx->stream));
+        PRB_HIP(launch_gather_recs_to_hits(recs, w.idxB.as<uint32_t>(), out, n, ctx->stream));
         *perm_out = w.idxB.as<uint32_t>();
         return PRB_OK;
       }
     }
   }
+  // the general form works on the fields as arrays
+  if ((rc = w.hitsTmp.ensure(hits_bytes(n)))) return rc;
+  const HitSoA in = carve_hits(w.hitsTmp, n);
+  PRB_HIP(launch_gather_recs_to_hits(recs, nullptr, in, n, ctx->stream));
   if ((rc = w.kE.ensure(N * 8)) || (rc = w.kL.ensure(N * 4)) || (rc = w.kQ.ensure(N * 4)) || (rc = w.kP.ensure(N * 8)) ||
       (rc = w.kTmp.ensure(N * 8)) || (rc = w.kTmp2.ensure(N * 8)) || (rc = w.idxA.ensure(N * 4)) ||
       (rc = w.idxB.ensure(N * 4)))
@@ -746,8 +750,9 @@ static int filter_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, do
 }
 
 // Drops the hits whose energy is above `thr` (they cannot survive CheckRedundancy nor influence
-// it, see k_flag_not_above): out <- the kept hits of in, in order; *idx_out[i] = index in `in`.
-static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n, double thr, DevBuf &idxbuf, HitSoA out,
+// it, see k_flag_not_above): recbuf <- the kept hits of in, in order, as records for the sort that
+// follows; idxbuf[i] = index in `in`.
+static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n, double thr, DevBuf &idxbuf, DevBuf &recbuf,
                          int64_t *m) {
   int rc;
   *m = 0;
@@ -765,7 +770,8 @@ static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n,
   PRB_HIP(hipMemcpyAsync(&cnt, w.count.p, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
   PRB_HIP(hipStreamSynchronize(ctx->stream));
   *m = (int64_t)cnt;
-  PRB_HIP(launch_gather_hits(in, idxbuf.as<uint32_t>(), out, *m, ctx->stream));
+  if ((rc = recbuf.ensure(std::max<size_t>(cnt, 1) * sizeof(HitRec)))) return rc;
+  PRB_HIP(launch_gather_hits_to_recs(in, idxbuf.as<uint32_t>(), recbuf.as<HitRec>(), *m, ctx->stream));
   return PRB_OK;
 }
 
@@ -852,18 +858,16 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, max_qlen, ctx->stream));
   if ((rc = ctx->time_end("ungapped", 1))) return rc;
   // hits above the -f threshold are dropped before the sort (they cannot survive the filter)
-  if ((rc = w.hitsB.ensure(hits_bytes(nseed)))) return rc;
-  HitSoA A2 = carve_hits(w.hitsB, nseed);
   int64_t m1 = 0;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = compact_below(ctx, w, A, nseed, opts.interaction_threshold, w.cidx, A2, &m1))) return rc;
+  if ((rc = compact_below(ctx, w, A, nseed, opts.interaction_threshold, w.cidx, w.hitsB, &m1))) return rc;
   if ((rc = ctx->time_end("filter", 2))) return rc;
   if (m1 == 0) return PRB_OK;
   if ((rc = w.hitsC.ensure(hits_bytes(m1)))) return rc;
   HitSoA B = carve_hits(w.hitsC, m1);
   uint32_t *perm = nullptr;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, A2, B, m1, qb->nq, sb, &perm))) return rc;
+  if ((rc = sort_hits(ctx, w, w.hitsB.as<HitRec>(), B, m1, qb->nq, sb, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nung = 0;
   if ((rc = ctx->time_begin())) return rc;
@@ -1033,15 +1037,14 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   }
 
   // ---- final sort + filter (hits above the -g threshold dropped first) ----
-  HitSoA G2 = carve_hits(w.hitsB, nung);
   int64_t m2 = 0;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = compact_below(ctx, w, G, nung, opts.final_threshold, w.cidx, G2, &m2))) return rc;
+  if ((rc = compact_below(ctx, w, G, nung, opts.final_threshold, w.cidx, w.hitsB, &m2))) return rc;
   if ((rc = ctx->time_end("filter", 2))) return rc;
   if (m2 == 0) return PRB_OK;
   HitSoA S = carve_hits(w.hitsC, m2); // G is dead after the compaction
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, G2, S, m2, qb->nq, sb, &perm))) return rc;
+  if ((rc = sort_hits(ctx, w, w.hitsB.as<HitRec>(), S, m2, qb->nq, sb, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nfin = 0;
   if ((rc = ctx->time_begin())) return rc;
@@ -1050,8 +1053,9 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   hs->counts[2] += nfin;
   if (nfin == 0) return PRB_OK;
   // final hits, and for each the index of its pre-gapped state in U (for the traceback):
-  // final -> sorted position -> position in G2 -> index in U
-  HitSoA F = carve_hits(w.hitsB, nfin); // G2 is dead after the sort
+  // final -> sorted position -> position in the compacted list -> index in U
+  if ((rc = w.hitsB.ensure(hits_bytes(nfin)))) return rc; // (the records of the compacted list are dead after the sort)
+  HitSoA F = carve_hits(w.hitsB, nfin);
   PRB_HIP(launch_gather_hits(S, w.surv.as<uint32_t>(), F, nfin, ctx->stream));
   if ((rc = w.subset2.ensure((size_t)nfin * 4))) return rc;
   PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset2.as<uint32_t>(), nfin, ctx->stream));

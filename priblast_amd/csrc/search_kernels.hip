@@ -442,6 +442,22 @@ __global__ __launch_bounds__(kBlock) void k_make_packed_keys(HitSoA h, int64_t n
   idx[i] = (uint32_t)i;
 }
 
+__global__ __launch_bounds__(kBlock) void k_make_packed_keys_recs(const HitRec *__restrict__ h, int64_t n, PackedKeyInfo f,
+                                                                  uint64_t *key, uint64_t *k_energy, uint32_t *idx) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const HitRec r = h[i];
+  const uint64_t eb = (uint64_t)__double_as_longlong(r.e_tot);
+  k_energy[i] = (eb >> 63) ? ~eb : (eb | 0x8000000000000000ull);
+  uint64_t k = (uint64_t)(uint32_t)(r.query - f.qmin);
+  k = (k << f.bd) | (uint32_t)r.db_sp;
+  k = (k << f.bq) | (uint32_t)r.q_sp;
+  k = (k << f.bl) | (uint32_t)(f.lmax - US(r.db_len));
+  k = (k << f.bl) | (uint32_t)(f.lmax - US(r.q_len));
+  key[i] = k;
+  idx[i] = (uint32_t)i;
+}
+
 constexpr int kMaxTieRun = 4096;
 __global__ __launch_bounds__(kBlock) void k_fix_ties(const uint64_t *__restrict__ key, uint64_t *e, uint32_t *perm, int64_t n,
                                                      int32_t *too_long) {
@@ -488,6 +504,41 @@ __global__ __launch_bounds__(kBlock) void k_gather_hits(HitSoA s, const uint32_t
   d.e_acc[i] = s.e_acc[j];
   d.e_hyb[i] = s.e_hyb[j];
   d.e_tot[i] = s.e_tot[j];
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_hits_to_recs(HitSoA s, const uint32_t *idx, HitRec *d, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = idx[i];
+  HitRec r;
+  r.q_sp = s.q_sp[j];
+  r.db_sp = s.db_sp[j];
+  r.q_len = s.q_len[j];
+  r.db_len = s.db_len[j];
+  r.db_id = s.db_id[j];
+  r.db_id_start = s.db_id_start[j];
+  r.query = s.query[j];
+  r.pad0 = 0;
+  r.e_acc = s.e_acc[j];
+  r.e_hyb = s.e_hyb[j];
+  r.e_tot = s.e_tot[j];
+  r.pad1 = 0;
+  d[i] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_gather_recs_to_hits(const HitRec *__restrict__ s, const uint32_t *idx, HitSoA d, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const HitRec r = s[idx ? (int64_t)idx[i] : i];
+  d.q_sp[i] = r.q_sp;
+  d.db_sp[i] = r.db_sp;
+  d.q_len[i] = r.q_len;
+  d.db_len[i] = r.db_len;
+  d.db_id[i] = r.db_id;
+  d.db_id_start[i] = r.db_id_start;
+  d.query[i] = r.query;
+  d.e_acc[i] = r.e_acc;
+  d.e_hyb[i] = r.e_hyb;
+  d.e_tot[i] = r.e_tot;
 }
 
 // SoA hits -> the C ABI's records (include/priblast_hip.h), so that one copy brings them to the host.
@@ -703,6 +754,22 @@ hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *ds
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_gather_hits, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_gather_hits_to_recs(const HitSoA &src, const uint32_t *idx, HitRec *dst, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_hits_to_recs, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_gather_recs_to_hits(const HitRec *src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_recs_to_hits, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_make_packed_keys_recs(const HitRec *hits, int64_t n, const PackedKeyInfo &f, uint64_t *key, uint64_t *k_energy,
+                                        uint32_t *idx, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_make_packed_keys_recs, grid_for(n), dim3(kBlock), 0, s, hits, n, f, key, k_energy, idx);
   return hipGetLastError();
 }
 hipError_t launch_pack_hits(const HitSoA &src, int64_t n, const int32_t *bp_count, const int64_t *bp_off, int64_t bp_base,

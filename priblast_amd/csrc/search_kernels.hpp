@@ -122,6 +122,19 @@ hipError_t launch_pack_hits(const HitSoA &src, int64_t n, const int32_t *bp_coun
                             void *out, hipStream_t s);
 hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
+// The hits between a threshold compaction and the sort behind it, one 64-byte record each: the sort
+// ends in a gather in random order, which then costs one cache line per hit instead of one per field.
+struct alignas(16) HitRec {
+  int32_t q_sp, db_sp, q_len, db_len, db_id, db_id_start, query, pad0;
+  double e_acc, e_hyb, e_tot;
+  int64_t pad1;
+};
+static_assert(sizeof(HitRec) == 64, "one cache line half, two per 128-byte line");
+hipError_t launch_gather_hits_to_recs(const HitSoA &src, const uint32_t *idx, HitRec *dst, int64_t n, hipStream_t s);
+// idx == nullptr: in order
+hipError_t launch_gather_recs_to_hits(const HitRec *src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
+hipError_t launch_make_packed_keys_recs(const HitRec *hits, int64_t n, const PackedKeyInfo &f, uint64_t *key, uint64_t *k_energy,
+                                        uint32_t *idx, hipStream_t s);
 hipError_t launch_flag_not_above(const double *e_tot, int64_t n, double thr, uint8_t *keep, hipStream_t s);
 hipError_t launch_mark_first(const int32_t *query, int64_t n, uint8_t *first, hipStream_t s);
 // ---- redundancy filter on a sorted list ----
