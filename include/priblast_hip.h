@@ -81,7 +81,8 @@ int prb_ctx_synchronize(prb_ctx *ctx);
  * reset, and launch counts: "raccess", "seed", "ungapped", "sort", "filter", "gapped" (LDS tier 0),
  * "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow" (HBM-scratch kernel), "traceback", "traceback_slow";
  * host wall-clock pseudo stages: "host_dfs" (background seed DFS), "host_dfs_wait",
- * "host_search_range", "host_cands", "host_drain_tail". */
+ * "host_search_range", "host_cands", "host_drain_tail", "host_download" (the synchronous copy of
+ * the hits of last_stage 1 / 2). */
 int prb_ctx_stage_ms(prb_ctx *ctx, const char *stage, double *ms, int64_t *launches);
 void prb_ctx_reset_timers(prb_ctx *ctx);
 

@@ -181,3 +181,27 @@ def test_binary_hit_file_to_text(tmp_path):
         _write_hit_file(src, style, header, tabs, bad)
         r = subprocess.run([capi.BIN_PATH, "txt", "-i", src, "-o", dst], capture_output=True, text=True)
         assert r.returncode == 1 and "corrupt" in r.stderr
+
+
+def test_header_lists_every_stage_timer():
+    """include/priblast_hip.h documents the names prb_ctx_stage_ms answers to: every timer the library
+    records (time_end("...") / HostTimer(ctx, "...") / the tier timer table) is named there, and
+    bench.py reports all of them."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for name in ("capi_search.hip", "capi_core.hip"):
+        with open(os.path.join(root, "priblast_amd", "csrc", name)) as f:
+            src += f.read()
+    names = set(re.findall(r'time_end\("([a-z_0-9]+)"', src)) | set(re.findall(r'HostTimer \w+\(ctx, "([a-z_0-9]+)"\)', src))
+    m = re.search(r'kTierTimer\[\d+\] = \{([^}]*)\}', src)
+    names |= set(re.findall(r'"([a-z_0-9]+)"', m.group(1)))
+    names |= set(re.findall(r'timers\["([a-z_0-9]+)"\]', src))
+    assert {"raccess", "seed", "ungapped", "gapped", "gapped_t3", "gapped_slow", "host_dfs"} <= names
+    with open(os.path.join(root, "include", "priblast_hip.h")) as f:
+        header = f.read()
+    with open(os.path.join(root, "bench.py")) as f:
+        bench = f.read()
+    for n in sorted(names):
+        assert f'"{n}"' in header, n
+        assert f'"{n}"' in bench, n
