@@ -205,3 +205,20 @@ def test_header_lists_every_stage_timer():
     for n in sorted(names):
         assert f'"{n}"' in header, n
         assert f'"{n}"' in bench, n
+
+
+def test_integration_doc_lists_every_environment_variable():
+    """Every PRB_* variable the library, the command line or bench.py reads is in INTEGRATION.md's table."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for pat in ("priblast_amd/csrc/*.hip", "priblast_amd/csrc/*.cpp", "priblast_amd/host/*.cpp"):
+        for path in glob.glob(os.path.join(root, pat)):
+            with open(path) as f:
+                names |= set(re.findall(r'getenv\("(PRB_[A-Z_0-9]+)"\)', f.read()))
+    assert {"PRB_DEVICES", "PRB_BATCH", "PRB_SEARCH_PAIRS", "PRB_GAPPED_FIRST_TIER"} <= names
+    with open(os.path.join(root, "INTEGRATION.md")) as f:
+        doc = f.read()
+    for n in sorted(names):
+        assert f"`{n}`" in doc, n
