@@ -39,7 +39,11 @@ extern "C" {
 #define PRB_ERR_NOMEM (-4)
 #define PRB_ERR_STATE (-5)
 
-typedef struct prb_ctx prb_ctx;       /* one GPU: stream, parameter tables, workspaces */
+typedef struct prb_ctx prb_ctx;       /* one GPU: stream, parameter tables, workspaces.  A context is used by one
+                                       * host thread at a time; several contexts may share a device (each has its
+                                       * own stream), and query batches / databases made under one of them can be
+                                       * used under another one of the same device - e.g. the accessibilities of the
+                                       * next batch computed under a second context while the first one searches */
 typedef struct prb_db prb_db;         /* database pages resident in HBM */
 typedef struct prb_qbatch prb_qbatch; /* a batch of queries: enc + SA + accessibilities */
 typedef struct prb_hitset prb_hitset; /* result of prb_search_page, host side */
@@ -147,6 +151,22 @@ const int32_t *prb_hitset_basepairs(const prb_hitset *hs, int64_t *count);
 /* number of hits per stage for the whole call: seeds, after ungapped+filter, final */
 void prb_hitset_counts(const prb_hitset *hs, int64_t counts[3]);
 void prb_hitset_free(prb_hitset *hs);
+
+/* ---- output: SaveMyResults (rna_interaction_search.cpp:322-369) ----
+ * The result lines of one batch of queries, grouped query by query and page by page and numbered
+ * from id0 on (the `Id` column; MergeOutput, rna_interaction_search.cpp:464-476), written to the file
+ * descriptor `fd` (fd < 0: formatted and counted only).  pages[p] = the hits of the batch against
+ * page p with their pair array, as prb_hitset_hits / prb_hitset_basepairs return them (or as they
+ * arrived from another rank); hits ascending by `query`.  Host threads format in parallel. */
+typedef struct prb_page_hits {
+  const prb_hit *hits;
+  int64_t nhits;
+  const int32_t *basepairs; /* int32[2 * npairs] */
+  int64_t npairs;
+} prb_page_hits;
+int prb_write_lines(const prb_db *db, int32_t nq, const char *const *qnames, const int32_t *qlen_unmasked,
+                    const prb_page_hits *pages, int32_t npages, int32_t output_style, int64_t id0, int fd,
+                    int64_t *lines, int64_t *bytes);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,10 @@ class Hit(ctypes.Structure):
                 ("bp_count", c_i32), ("bp_offset", c_i64)]
 
 
+class PageHits(ctypes.Structure):
+    _fields_ = [("hits", ctypes.c_void_p), ("nhits", c_i64), ("basepairs", ctypes.c_void_p), ("npairs", c_i64)]
+
+
 HIT_DTYPE = np.dtype([("q_sp", "<i4"), ("db_sp", "<i4"), ("q_len", "<i4"), ("db_len", "<i4"), ("db_id", "<i4"),
                       ("db_id_start", "<i4"), ("e_acc", "<f8"), ("e_hyb", "<f8"), ("e_tot", "<f8"),
                       ("query", "<i4"), ("bp_count", "<i4"), ("bp_offset", "<i8")])
@@ -75,6 +79,8 @@ SYMBOLS = {
     "prb_hitset_basepairs": (ctypes.c_void_p, [ctypes.c_void_p, P(c_i64)]),
     "prb_hitset_counts": (None, [ctypes.c_void_p, P(c_i64)]),
     "prb_hitset_free": (None, [ctypes.c_void_p]),
+    "prb_write_lines": (ctypes.c_int, [ctypes.c_void_p, c_i32, P(ctypes.c_char_p), ctypes.c_void_p, ctypes.c_void_p, c_i32,
+                                       c_i32, c_i64, ctypes.c_int, P(c_i64), P(c_i64)]),
 }
 
 _lib = None
@@ -304,3 +310,21 @@ def search_page(ctx, qb, db, page, opts=None, last_stage=3):
     else:
         bp = np.zeros((0, 2), np.int32)
     return hits, bp, tuple(counts)
+
+
+def write_lines(db, qnames, qlen_unmasked, pages, output_style=0, id0=0, fd=-1):
+    """Result lines (SaveMyResults) of one batch: pages = [(hits, bp)] per database page as search_page returns
+    them.  -> (lines, bytes) written to the descriptor fd (-1: formatted and counted only)."""
+    arr = (PageHits * len(pages))()
+    keep = []
+    for k, (hits, bp) in enumerate(pages):
+        hits = np.ascontiguousarray(hits)
+        bp = np.ascontiguousarray(bp, np.int32)
+        keep += [hits, bp]
+        arr[k] = PageHits(hits.ctypes.data if len(hits) else None, len(hits), bp.ctypes.data if bp.size else None, bp.size // 2)
+    names = (ctypes.c_char_p * len(qnames))(*[n.encode() for n in qnames])
+    ql = np.ascontiguousarray(qlen_unmasked, np.int32)
+    lines, nbytes = c_i64(), c_i64()
+    _check(lib().prb_write_lines(db.h, len(qnames), names, ql.ctypes.data, arr, len(pages), output_style, id0, fd,
+                                 ctypes.byref(lines), ctypes.byref(nbytes)))
+    return lines.value, nbytes.value

@@ -22,6 +22,7 @@
 #include "context.hpp"
 #include "db_format.hpp"
 #include "encoder.hpp"
+#include "output.hpp"
 #include "search_kernels.hpp"
 #include "seed_dfs.hpp"
 #include "suffix_array.hpp"
@@ -203,6 +204,7 @@ struct prb_db {
   DbHeader hdr;
   std::vector<DbPage> pages;
   std::vector<PageMem> mem;
+  std::vector<SeqTable> tabs; // per page: what the result lines print about its sequences
 };
 
 struct prb_qbatch {
@@ -386,6 +388,11 @@ int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
       return rc;
     }
   }
+  db->tabs.resize(db->pages.size());
+  for (size_t i = 0; i < db->pages.size(); i++) {
+    const DbPage &pg = db->pages[i];
+    db->tabs[i] = SeqTable{pg.names, pg.seq_length, pg.seq_length_rep, pg.start_pos};
+  }
   *out = db;
   return PRB_OK;
 }
@@ -566,7 +573,7 @@ void prb_qbatch_destroy(prb_qbatch *qb) {
 }
 
 int prb_qbatch_accessibility(prb_ctx *ctx, prb_qbatch *qb, int32_t maximal_span, int32_t min_accessible_length) {
-  if (!ctx || !qb || qb->ctx != ctx) return PRB_ERR_ARG;
+  if (!ctx || !qb || qb->ctx->device != ctx->device) return PRB_ERR_ARG;
   const size_t n = (size_t)qb->off[qb->nq];
   PRB_HIP(hipSetDevice(ctx->device));
   PRB_HIP(hipMemsetAsync(qb->d_acc.p, 0, n * 4, ctx->stream));
@@ -1166,7 +1173,7 @@ extern "C" {
 
 int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, const prb_ris_opts *opts, int32_t last_stage,
                     prb_hitset **out) {
-  if (!ctx || !qb || !db || !opts || !out || qb->ctx != ctx || db->ctx != ctx || page < 0 ||
+  if (!ctx || !qb || !db || !opts || !out || qb->ctx->device != ctx->device || db->ctx->device != ctx->device || page < 0 ||
       page >= (int32_t)db->pages.size() || last_stage < 1 || last_stage > 3) {
     set_error("prb_search_page: bad argument");
     return PRB_ERR_ARG;
@@ -1313,5 +1320,53 @@ void prb_hitset_counts(const prb_hitset *hs, int64_t counts[3]) {
   for (int i = 0; i < 3; i++) counts[i] = hs ? hs->counts[i] : 0;
 }
 void prb_hitset_free(prb_hitset *hs) { delete hs; }
+
+int prb_write_lines(const prb_db *db, int32_t nq, const char *const *qnames, const int32_t *qlen_unmasked,
+                    const prb_page_hits *pages, int32_t npages, int32_t output_style, int64_t id0, int fd, int64_t *lines,
+                    int64_t *bytes) {
+  if (!db || nq < 0 || (nq && (!qnames || !qlen_unmasked)) || !pages || npages != (int32_t)db->pages.size() ||
+      output_style < 0 || output_style > 1) {
+    set_error("prb_write_lines: bad argument");
+    return PRB_ERR_ARG;
+  }
+  try {
+    BatchView v;
+    std::vector<std::string> names((size_t)nq);
+    for (int32_t q = 0; q < nq; q++) names[q] = qnames[q];
+    v.nq = (size_t)nq;
+    v.names = names.data();
+    v.qlen_unmasked = qlen_unmasked;
+    for (int32_t p = 0; p < npages; p++) {
+      const prb_page_hits &ph = pages[p];
+      if (ph.nhits < 0 || ph.npairs < 0 || (ph.nhits && !ph.hits)) {
+        set_error("prb_write_lines: bad page");
+        return PRB_ERR_ARG;
+      }
+      const int32_t nseq = db->pages[p].nseq;
+      for (int64_t i = 0; i < ph.nhits; i++) { // the records may come from another process: check before indexing
+        const prb_hit &x = ph.hits[i];
+        if (x.query < 0 || x.query >= nq || x.db_id < 0 || x.db_id >= nseq || x.bp_count < 0 || x.bp_offset < 0 ||
+            x.bp_offset + x.bp_count > ph.npairs || (i && x.query < ph.hits[i - 1].query)) {
+          set_error("prb_write_lines: hit record " + std::to_string(i) + " of page " + std::to_string(p) + " is inconsistent");
+          return PRB_ERR_ARG;
+        }
+      }
+      v.pages.push_back(PageHits{ph.hits, ph.nhits, ph.basepairs, ph.npairs});
+    }
+    LineSink sink;
+    sink.fd = fd;
+    const int64_t next = format_batch(v, db->tabs, output_style, id0, sink, format_threads());
+    if (lines) *lines = sink.lines;
+    if (bytes) *bytes = sink.bytes;
+    if (next < 0) {
+      set_error("prb_write_lines: write failed");
+      return PRB_ERR_IO;
+    }
+  } catch (const std::exception &e) {
+    set_error(std::string("prb_write_lines: ") + e.what());
+    return PRB_ERR_NOMEM;
+  }
+  return PRB_OK;
+}
 
 } // extern "C"

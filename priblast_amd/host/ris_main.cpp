@@ -26,8 +26,14 @@
 
 #include "../../include/priblast_hip.h"
 #include "fasta.hpp"
+#include "output.hpp"
 
 namespace {
+
+using prb::BatchView;
+using prb::LineSink;
+using prb::PageHits;
+using prb::SeqTable;
 
 void usage() {
   std::puts("pRIblast-hip - RNA-RNA interaction search (ris step of pRIblast) on AMD Instinct GPUs\n"
@@ -77,27 +83,6 @@ struct Worker {
   prb_db *db = nullptr;
 };
 
-// What the output needs to know about the sequences of one database page.
-struct SeqTable {
-  std::vector<std::string> names;
-  std::vector<int32_t> len, len_unmasked, start_pos;
-};
-
-// The hits of one batch against one page, and a batch: plain arrays, wherever they live (hit sets
-// of the library, or a binary hit file read back).
-struct PageHits {
-  const prb_hit *h = nullptr;
-  int64_t n = 0;
-  const int32_t *bp = nullptr;
-  int64_t nbp = 0; // pairs
-};
-struct BatchView {
-  size_t nq = 0;
-  const std::string *names = nullptr; // [nq]
-  const int32_t *qlen_unmasked = nullptr;
-  std::vector<PageHits> pages;
-};
-
 // The hit sets of one batch (one per database page), waiting to be written.
 struct BatchJob {
   size_t index = 0, b0 = 0, nq = 0;
@@ -105,77 +90,6 @@ struct BatchJob {
   std::vector<prb_hitset *> pages;
   std::vector<int32_t> qlen_unmasked;
 };
-
-int format_threads() {
-  if (const char *e = std::getenv("PRB_HOST_THREADS")) return std::max(1, std::atoi(e));
-  const unsigned hw = std::thread::hardware_concurrency();
-  return (int)std::min(32u, std::max(1u, hw));
-}
-
-// Lines of one batch (SaveMyResults, rna_interaction_search.cpp:322-369), query by query and page
-// by page as the reference groups them, numbered from `id0` on.  The hits of a page arrive
-// grouped by query in ascending order (sub-batches of ascending queries, each sorted by
-// (query, db position)), so a query's hits are one contiguous range per page; queries are
-// formatted in parallel.
-int64_t format_batch(const BatchView &v, const std::vector<SeqTable> &tabs, int output_style, int64_t id0, std::FILE *out) {
-  const size_t nq = v.nq, np = v.pages.size();
-  std::vector<std::vector<int64_t>> first(np, std::vector<int64_t>(nq + 1, 0)); // first[p][q] = first hit of query q
-  for (size_t p = 0; p < np; p++) {
-    const int64_t n = v.pages[p].n;
-    const prb_hit *h = v.pages[p].h;
-    size_t q = 0;
-    for (int64_t i = 0; i < n; i++)
-      while (q < nq && (int64_t)q <= h[i].query) first[p][q++] = i;
-    while (q <= nq) first[p][q++] = n;
-  }
-  std::vector<int64_t> base(nq + 1, id0);
-  for (size_t q = 0; q < nq; q++) {
-    int64_t c = 0;
-    for (size_t p = 0; p < np; p++) c += first[p][q + 1] - first[p][q];
-    base[q + 1] = base[q] + c;
-  }
-  std::vector<std::string> text(nq);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(format_threads())
-  for (size_t q = 0; q < nq; q++) {
-    std::string &s = text[q];
-    s.reserve((size_t)(base[q + 1] - base[q]) * 80);
-    char buf[512];
-    int64_t id = base[q];
-    for (size_t p = 0; p < np; p++) {
-      const prb_hit *h = v.pages[p].h;
-      const int32_t *bp = v.pages[p].bp;
-      const SeqTable &tab = tabs[p];
-      for (int64_t i = first[p][q]; i < first[p][q + 1]; i++) {
-        const prb_hit &x = h[i];
-        const int32_t len = tab.len[x.db_id], sp = tab.start_pos[x.db_id];
-        std::snprintf(buf, sizeof buf, "%lld,", (long long)id++);
-        s += buf;
-        s += v.names[q];
-        std::snprintf(buf, sizeof buf, ",%d,", v.qlen_unmasked[q]);
-        s += buf;
-        s += tab.names[x.db_id];
-        std::snprintf(buf, sizeof buf, ",%d,%g,%g,%g,", tab.len_unmasked[x.db_id], x.e_acc, x.e_hyb, x.e_tot);
-        s += buf;
-        const int32_t *pp = bp + 2 * x.bp_offset;
-        auto fwd = [&](int32_t dbpos) { return (len - 1) - (dbpos - sp); }; // reversed text -> forward coordinate
-        if (output_style == 1) {
-          for (int32_t j = 0; j < x.bp_count; j++) {
-            std::snprintf(buf, sizeof buf, "(%d:%d) ", pp[2 * j], fwd(pp[2 * j + 1]));
-            s += buf;
-          }
-        } else if (x.bp_count > 0) {
-          const int32_t l = x.bp_count - 1;
-          std::snprintf(buf, sizeof buf, "(%d-%d:%d-%d) ", pp[0], pp[2 * l], fwd(pp[1]), fwd(pp[2 * l + 1]));
-          s += buf;
-        }
-        s += "\n";
-      }
-    }
-  }
-  for (auto &s : text)
-    if (!s.empty() && std::fwrite(s.data(), 1, s.size(), out) != s.size()) die("Error: can't write the output file");
-  return base[nq];
-}
 
 // ---- binary hit file (little-endian, the layouts of include/priblast_hip.h) ----------------------
 //   "PRBHITS\1" | i32 output_style | i32 npages | str header (the three text lines)
@@ -279,6 +193,9 @@ int txt_main(int argc, char **argv) {
   std::FILE *o = std::fopen(out.c_str(), "w");
   if (!o) die("Error: can't open output_file: " + out);
   put(o, header.data(), header.size());
+  if (std::fflush(o)) die("Error: can't write the output file");
+  LineSink sink;
+  sink.fd = fileno(o);
   int64_t id = 0;
   for (;;) {
     const int64_t tag = get<int64_t>(f);
@@ -319,7 +236,8 @@ int txt_main(int argc, char **argv) {
       ph.nbp = nbp;
       v.pages.push_back(ph);
     }
-    id = format_batch(v, tabs, output_style, id, o);
+    id = prb::format_batch(v, tabs, output_style, id, sink, prb::format_threads());
+    if (id < 0) die("Error: can't write the output file");
   }
   std::fclose(f);
   if (std::fclose(o)) die("Error: can't write the output file");
@@ -434,6 +352,9 @@ int ris_main(int argc, char **argv) {
             "Interaction Energy, BasePair\n";
   if (a.binary) write_binary_head(out, a.o.output_style, header, tabs);
   else put(out, header.data(), header.size());
+  if (std::fflush(out)) die("Error: can't write the output file");
+  LineSink sink; // text lines go straight to the descriptor (nothing else is written through `out` meanwhile)
+  sink.fd = fileno(out);
 
   const char *benv = std::getenv("PRB_BATCH");
   const size_t batch = std::max(1, benv ? std::atoi(benv) : 2048);
@@ -469,7 +390,8 @@ int ris_main(int argc, char **argv) {
         v.pages.push_back(ph);
       }
       if (a.binary) id += write_binary_batch(v, out);
-      else id = format_batch(v, tabs, a.o.output_style, id, out);
+      else if ((id = prb::format_batch(v, tabs, a.o.output_style, id, sink, prb::format_threads())) < 0)
+        die("Error: can't write the output file");
       for (prb_hitset *hs : job.pages) prb_hitset_free(hs);
       {
         std::lock_guard<std::mutex> lk(mu);

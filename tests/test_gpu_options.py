@@ -117,6 +117,45 @@ def test_1kb_vs_200kb_against_reference_binary(ctx, tmp_path):
     assert a == b
 
 
+def test_2kb_vs_2kb_c3_shape_against_reference_binary(ctx, tmp_path):
+    """BASELINE configs[2] shape in miniature: 16 x 2 kb queries vs 800 x 2 kb database (1.6 M characters),
+    the GPU command line against the unmodified reference's strict build run on the box: same result
+    lines (energies as printed, coordinates, Id aside)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic
+    from priblast_amd import capi
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.strict")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    gen_synthetic.write_fasta(dbfa, gen_synthetic.gen_fixed(800, 2000, 1, "db"))
+    gen_synthetic.write_fasta(qfa, gen_synthetic.gen_fixed(16, 2000, 2, "q"))
+    subprocess.run([capi.BIN_PATH, "db", "-i", dbfa, "-o", str(tmp_path / "db")], check=True)
+    env = dict(os.environ, OMP_NUM_THREADS="16")
+    subprocess.run([ref, "ris", "-i", qfa, "-o", str(tmp_path / "ref.out"), "-d", str(tmp_path / "db"), "-p", str(tmp_path)],
+                   check=True, env=env, cwd=str(tmp_path))
+    subprocess.run([capi.BIN_PATH, "ris", "-i", qfa, "-o", str(tmp_path / "gpu.out"), "-d", str(tmp_path / "db")], check=True,
+                   env=dict(os.environ, PRB_BATCH="6"))
+
+    def body(p):
+        with open(p) as f:
+            return sorted(l.split(",", 1)[1] for l in f.read().splitlines()[3:])
+    a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
+    assert len(b) > 100000
+    if a != b:  # leave the evidence where gpurun brings it back
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        sa, sb = set(a), set(b)
+        with open(os.path.join(out, "c3shape_diff.txt"), "w") as f:
+            f.write(f"gpu {len(a)} lines, reference {len(b)} lines\n")
+            for l in sorted(sa - sb)[:200]:
+                f.write("gpu only: " + l + "\n")
+            for l in sorted(sb - sa)[:200]:
+                f.write("ref only: " + l + "\n")
+    assert a == b
+
+
 @pytest.mark.parametrize("repeat_flag", [1, 2])
 def test_repeat_flags_against_reference_binary(tmp_path, repeat_flag):
     """Soft-masked (lower-case) stretches with `db -r 1` / `-r 2` (encoder.cpp:38-89): the database

@@ -222,3 +222,63 @@ def test_integration_doc_lists_every_environment_variable():
         doc = f.read()
     for n in sorted(names):
         assert f"`{n}`" in doc, n
+
+
+def test_txt_converter_prints_like_the_reference_stream(lib, tmp_path):
+    """The result lines (SaveMyResults, rna_interaction_search.cpp:322-369) print doubles as `ostream <<`
+    does (= "%g") and turn reversed page coordinates into forward ones: a synthetic binary hit file with
+    awkward values through `pRIblast-hip txt` (no GPU needed) against the same lines formatted here."""
+    import struct
+    import subprocess
+    rng = np.random.default_rng(7)
+    specials = [0.0, -0.0, 1e-5, -1e-5, 9.99999e-5, 123456.5, -999999.5, 999999.4, 1e6, -8.0, -8.05, -12.3456789, 1e-300,
+                -0.000123456789, 100000.0, 0.1 + 0.2, -10.55, 5e-324, 1.5e300]
+    nq, nseq = 3, 4
+    qnames = [f"q{i} desc" for i in range(nq)]
+    qlen = [100, 200, 300]
+    dnames = [f"db{i}|x" for i in range(nseq)]
+    dlen = [500, 400, 300, 200]
+    start = np.concatenate([[0], np.cumsum(np.array(dlen) + 1)[:-1]]).astype(int)
+    n = 9000  # more than one piece per query
+    hits = np.zeros(n, capi.HIT_DTYPE)
+    hits["query"] = np.sort(rng.integers(0, nq, n))
+    hits["db_id"] = rng.integers(0, nseq, n)
+    vals = np.concatenate([specials, rng.normal(-10, 5, 3 * n)])[:3 * n]
+    rng.shuffle(vals)
+    hits["e_acc"], hits["e_hyb"], hits["e_tot"] = vals[:n], vals[n:2 * n], vals[2 * n:]
+    hits["bp_count"] = rng.integers(1, 5, n)
+    hits["bp_offset"] = np.concatenate([[0], np.cumsum(hits["bp_count"])[:-1]])
+    npairs = int(hits["bp_count"].sum())
+    bp = np.zeros((npairs, 2), np.int32)
+    bp[:, 0] = rng.integers(0, 300, npairs)
+    bp[:, 1] = np.repeat(start[hits["db_id"]], hits["bp_count"]) + rng.integers(0, 200, npairs)
+    header = "RIblast ris result\nheader two\nheader three\n"
+
+    def s(x):
+        b = x.encode()
+        return struct.pack("<i", len(b)) + b
+    for style in (0, 1):
+        blob = b"PRBHITS\x01" + struct.pack("<ii", style, 1) + s(header)
+        blob += struct.pack("<i", nseq)
+        for i in range(nseq):
+            blob += struct.pack("<iii", dlen[i], dlen[i] - 1, int(start[i])) + s(dnames[i])
+        blob += struct.pack("<qq", ord("B"), nq)
+        for i in range(nq):
+            blob += s(qnames[i]) + struct.pack("<i", qlen[i])
+        blob += struct.pack("<qq", n, npairs) + hits.tobytes() + bp.tobytes()
+        blob += struct.pack("<qq", ord("E"), n)
+        src, dst = tmp_path / f"h{style}.prb", tmp_path / f"h{style}.txt"
+        src.write_bytes(blob)
+        subprocess.run([capi.BIN_PATH, "txt", "-i", str(src), "-o", str(dst)], check=True)
+        want = [header]
+        for k, h in enumerate(hits):
+            d = int(h["db_id"])
+            pp = bp[h["bp_offset"]:h["bp_offset"] + h["bp_count"]]
+            fwd = lambda x: (dlen[d] - 1) - (int(x) - int(start[d]))
+            if style == 1:
+                pairs = "".join(f"({a}:{fwd(b)}) " for a, b in pp)
+            else:
+                pairs = f"({pp[0][0]}-{pp[-1][0]}:{fwd(pp[0][1])}-{fwd(pp[-1][1])}) "
+            want.append(f"{k},{qnames[h['query']]},{qlen[h['query']]},{dnames[d]},{dlen[d] - 1},"
+                        f"{'%g' % h['e_acc']},{'%g' % h['e_hyb']},{'%g' % h['e_tot']},{pairs}\n")
+        assert dst.read_text() == "".join(want)
