@@ -308,20 +308,25 @@ def main():
             state["prep"] = Prep(k + 1)
         t2 = time.perf_counter()
         total = [0, 0, 0]
-        pages = []
+        sets = []
         for page in range(db.npages):
-            hits, bp, counts = capi.search_page(ctx, qb, db, page, opts, 3)
-            pages.append((hits, bp))
+            hs = capi.search_page_hs(ctx, qb, db, page, opts, 3)
+            sets.append(hs)
             for i in range(3):
-                total[i] += counts[i]
+                total[i] += hs.counts[i]
         qlen = [qb.length_unmasked(q) for q in range(hi - lo)]
         qb.close()
         wall["search (DFS + GPU stages + download)"] += time.perf_counter() - t2
         names = qnames[lo:hi]
-        if world > 1:  # final hit gather over RCCL: the records of every rank's batch to rank 0, which writes all lines
+        pages = [(hs.hits, hs.bp) for hs in sets]
+        if world > 1:  # final hit gather over RCCL: the packed records of every rank's batch, device to device, to rank 0
             t3 = time.perf_counter()
-            pages, names, qlen = comm.gather_batch(pages, names, qlen)
+            got = comm.gather_batch(sets, qlen)
+            if rank == 0:
+                pages, nq_of, qlen = got
+                names = [n for r in range(world) for n in qnames[slice(*pdist.batch_slice(k, r, world, a.queries))]]
             wall["final hit gather (RCCL)"] += time.perf_counter() - t3
+        del sets
         join_format()  # at most one batch of lines in flight
         if rank == 0:
             nlines = sum(len(h) for h, _ in pages)

@@ -168,6 +168,32 @@ int prb_write_lines(const prb_db *db, int32_t nq, const char *const *qnames, con
                     const prb_page_hits *pages, int32_t npages, int32_t output_style, int64_t id0, int fd,
                     int64_t *lines, int64_t *bytes);
 
+/* ---- multi-GPU: one process per GPU, the final hit gather over RCCL (xGMI) ----
+ * Replaces MergeOutput's MPI token ring (rna_interaction_search.cpp:426-487) and, with the caller
+ * dealing batches to ranks, the area / dynamic schedulers (rna_interaction_search.cpp:143-160,
+ * 202-230).  Queries are independent end to end: this gather is the only exchange of the `ris` step.
+ *   rank 0: prb_comm_unique_id(id); the 128 bytes reach the other ranks by any side channel (a file,
+ *   torch.distributed, MPI ...); every rank: prb_comm_create(ctx, nranks, rank, id, &comm).
+ * From then on the final hit sets of `ctx` also keep their packed records in HBM, and
+ * prb_gather_hits - a collective, called by every rank once per (batch round, database page) -
+ * moves them device to device: on `root`, *out is a new hit set with the hits of all ranks in rank
+ * order, `query` shifted by the number of queries of the lower ranks and pair offsets rebased;
+ * prb_hitset_gathered_queries gives every rank's batch size and the unmasked lengths of all the
+ * queries in the same order.  Elsewhere *out = NULL.  A rank without a batch in this round passes mine = NULL,
+ * nq = 0.  The gathered hit set borrows a pinned buffer of the communicator until it is
+ * freed with prb_hitset_free (from any thread; before prb_comm_destroy). */
+typedef struct prb_comm prb_comm;
+#define PRB_COMM_ID_BYTES 128
+int prb_comm_unique_id(char id[PRB_COMM_ID_BYTES]);
+int prb_comm_create(prb_ctx *ctx, int32_t nranks, int32_t rank, const char id[PRB_COMM_ID_BYTES], prb_comm **out);
+void prb_comm_destroy(prb_comm *comm);
+int prb_gather_hits(prb_comm *comm, const prb_hitset *mine, int32_t nq, const int32_t *qlen_unmasked, int32_t root,
+                    prb_hitset **out);
+int prb_hitset_gathered_queries(const prb_hitset *hs, int32_t *nranks, const int32_t **nq_of_rank,
+                                const int32_t **qlen_unmasked);
+/* keep (on != 0) the packed records of later final hit sets in HBM without a communicator (tests) */
+void prb_ctx_keep_device_records(prb_ctx *ctx, int32_t on);
+
 #ifdef __cplusplus
 }
 #endif

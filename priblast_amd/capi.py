@@ -79,6 +79,12 @@ SYMBOLS = {
     "prb_hitset_basepairs": (ctypes.c_void_p, [ctypes.c_void_p, P(c_i64)]),
     "prb_hitset_counts": (None, [ctypes.c_void_p, P(c_i64)]),
     "prb_hitset_free": (None, [ctypes.c_void_p]),
+    "prb_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "prb_comm_create": (ctypes.c_int, [ctypes.c_void_p, c_i32, c_i32, ctypes.c_char_p, P(ctypes.c_void_p)]),
+    "prb_comm_destroy": (None, [ctypes.c_void_p]),
+    "prb_gather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p, c_i32, P(ctypes.c_void_p)]),
+    "prb_hitset_gathered_queries": (ctypes.c_int, [ctypes.c_void_p, P(c_i32), P(P(c_i32)), P(P(c_i32))]),
+    "prb_ctx_keep_device_records": (None, [ctypes.c_void_p, c_i32]),
     "prb_write_lines": (ctypes.c_int, [ctypes.c_void_p, c_i32, P(ctypes.c_char_p), ctypes.c_void_p, ctypes.c_void_p, c_i32,
                                        c_i32, c_i64, ctypes.c_int, P(c_i64), P(c_i64)]),
 }
@@ -288,28 +294,79 @@ class _HitSetView:
         self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
 
-def search_page(ctx, qb, db, page, opts=None, last_stage=3):
-    """-> (hits: structured array HIT_DTYPE, bp: int32 [n,2], counts (seed, ungapped, final)).
-    The arrays are views of the hit set (freed when the last of them goes away)."""
+class HitSet:
+    """A prb_hitset: .hits (structured array HIT_DTYPE) and .bp (int32 [n, 2]) are views of the library's
+    memory (no copy); they keep the hit set alive, which is freed when the last of them goes away."""
+
+    def __init__(self, handle):
+        self._owner = _HitSetOwner(handle)
+        self.h = handle
+        counts = (c_i64 * 3)()
+        lib().prb_hitset_counts(handle, counts)
+        self.counts = tuple(counts)
+        n = lib().prb_hitset_size(handle)
+        cnt = c_i64()
+        p = lib().prb_hitset_basepairs(handle, ctypes.byref(cnt))
+        if n:
+            self.hits = np.asarray(_HitSetView(self._owner, lib().prb_hitset_hits(handle), n * HIT_DTYPE.itemsize)).view(HIT_DTYPE)
+        else:
+            self.hits = np.zeros(0, HIT_DTYPE)
+        if cnt.value:
+            self.bp = np.asarray(_HitSetView(self._owner, p, cnt.value * 8)).view(np.int32).reshape(-1, 2)
+        else:
+            self.bp = np.zeros((0, 2), np.int32)
+
+
+def search_page_hs(ctx, qb, db, page, opts=None, last_stage=3):
+    """prb_search_page -> HitSet"""
     o = opts or default_opts()
     h = ctypes.c_void_p()
     _check(lib().prb_search_page(ctx.h, qb.h, db.h, page, ctypes.byref(o), last_stage, ctypes.byref(h)))
-    counts = (c_i64 * 3)()
-    lib().prb_hitset_counts(h, counts)
-    n = lib().prb_hitset_size(h)
-    cnt = c_i64()
-    p = lib().prb_hitset_basepairs(h, ctypes.byref(cnt))
-    if n == 0:
-        lib().prb_hitset_free(h)
-        return np.zeros(0, HIT_DTYPE), np.zeros((0, 2), np.int32), tuple(counts)
+    return HitSet(h)
 
-    owner = _HitSetOwner(h)
-    hits = np.asarray(_HitSetView(owner, lib().prb_hitset_hits(h), n * HIT_DTYPE.itemsize)).view(HIT_DTYPE)
-    if cnt.value:
-        bp = np.asarray(_HitSetView(owner, p, cnt.value * 8)).view(np.int32).reshape(-1, 2)
-    else:
-        bp = np.zeros((0, 2), np.int32)
-    return hits, bp, tuple(counts)
+
+def search_page(ctx, qb, db, page, opts=None, last_stage=3):
+    """-> (hits: structured array HIT_DTYPE, bp: int32 [n,2], counts (seed, ungapped, final)).
+    The arrays are views of the hit set (freed when the last of them goes away)."""
+    hs = search_page_hs(ctx, qb, db, page, opts, last_stage)
+    return hs.hits, hs.bp, hs.counts
+
+
+class Comm:
+    """prb_comm: the RCCL communicator of the final hit gather (one process per GPU)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(Comm.ID_BYTES)
+        _check(lib().prb_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, nranks, rank, uid):
+        h = ctypes.c_void_p()
+        _check(lib().prb_comm_create(ctx.h, nranks, rank, uid, ctypes.byref(h)))
+        self.h, self.nranks, self.rank = h, nranks, rank
+
+    def close(self):
+        if self.h:
+            lib().prb_comm_destroy(self.h)
+            self.h = None
+
+    def gather(self, hitset, qlen_unmasked, root=0):
+        """collective; on root -> (HitSet of all ranks, nq per rank, unmasked lengths of all queries), else None"""
+        ql = np.ascontiguousarray(qlen_unmasked, np.int32)
+        out = ctypes.c_void_p()
+        _check(lib().prb_gather_hits(self.h, hitset.h if hitset is not None else None, len(ql), ql.ctypes.data if len(ql) else None,
+                                     root, ctypes.byref(out)))
+        if self.rank != root:
+            return None
+        n, pn, pq = c_i32(), P(c_i32)(), P(c_i32)()
+        _check(lib().prb_hitset_gathered_queries(out, ctypes.byref(n), ctypes.byref(pn), ctypes.byref(pq)))
+        nq_of = np.ctypeslib.as_array(pn, (n.value,)).copy()
+        total = int(nq_of.sum())
+        qall = np.ctypeslib.as_array(pq, (total,)).copy() if total else np.zeros(0, np.int32)
+        return HitSet(out), nq_of, qall
 
 
 def write_lines(db, qnames, qlen_unmasked, pages, output_style=0, id0=0, fd=-1):

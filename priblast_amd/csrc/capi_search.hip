@@ -22,6 +22,7 @@
 #include "context.hpp"
 #include "db_format.hpp"
 #include "encoder.hpp"
+#include "hitset.hpp"
 #include "output.hpp"
 #include "search_kernels.hpp"
 #include "seed_dfs.hpp"
@@ -39,31 +40,6 @@ struct SearchConstMem {
 struct PageMem {
   DevBuf seqs, sa, sa_seq, start_pos, seq_length, acc, cond;
   PageDev view{};
-};
-
-// pinned host staging buffer that only grows
-struct PinnedBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return PRB_OK;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-    const size_t want = bytes + bytes / 4;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
-      p = nullptr;
-      set_error("out of pinned host memory allocating " + std::to_string(want) + " bytes");
-      return PRB_ERR_NOMEM;
-    }
-    cap = want;
-    return PRB_OK;
-  }
-  void release() {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-  }
 };
 
 // buffers reused across prb_search_page calls
@@ -219,21 +195,6 @@ struct prb_qbatch {
   bool have_acc = false;
   int32_t W = 0, delta = 0;
   QBatchDev view{};
-};
-
-namespace prb {
-struct Drainer;
-}
-struct prb_hitset {
-  std::vector<prb_hit> hits;
-  std::vector<int32_t> bp;
-  int64_t counts[3] = {0, 0, 0};
-  int64_t slow_hits = 0; // extensions that outgrew the LDS kernel
-  // while prb_search_page runs: results of finished sub-batches are appended by a background
-  // thread; the main thread only keeps the totals it needs for the offsets
-  prb::Drainer *drain = nullptr;
-  int64_t hits_total = 0, bp_ints_total = 0;
-  int next_slot = 0;
 };
 
 namespace prb {
@@ -1159,6 +1120,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     PRB_HIP(hipMemcpyAsync(w.pin_hits[slot].p, w.packed.p, (size_t)nfin * sizeof(prb_hit), hipMemcpyDeviceToHost, ctx->stream));
     if (nbp_ints)
       PRB_HIP(hipMemcpyAsync(w.pin_bp[slot].p, bp_src, (size_t)nbp_ints * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hs->on_device) { // device copies for the final hit gather (prb_gather_hits): no re-upload later
+      if ((rc = hs->d_hits.append(w.packed.p, (size_t)nfin * sizeof(prb_hit), ctx->stream)) ||
+          (rc = hs->d_bp.append(bp_src, (size_t)nbp_ints * 4, ctx->stream)))
+        return rc;
+    }
     PRB_HIP(hipEventRecord(hs->drain->ev[slot], ctx->stream));
     hs->drain->submit(Drainer::Job{slot, nfin, nbp_ints});
     hs->hits_total += nfin;
@@ -1233,6 +1199,8 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     while (!done[q].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
   };
   auto *hs = new prb_hitset();
+  hs->device = ctx->device;
+  hs->on_device = ctx->keep_device_records && last_stage == 3;
   SearchWs &wsp = ws_of(ctx);
   Drainer drain(&hs->hits, &hs->bp, wsp.pin_hits, wsp.pin_bp);
   hs->drain = &drain;
@@ -1309,12 +1277,12 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   return PRB_OK;
 }
 
-int64_t prb_hitset_size(const prb_hitset *hs) { return hs ? (int64_t)hs->hits.size() : -1; }
-const prb_hit *prb_hitset_hits(const prb_hitset *hs) { return hs ? hs->hits.data() : nullptr; }
+int64_t prb_hitset_size(const prb_hitset *hs) { return !hs ? -1 : hs->ext_hits ? hs->ext_nhits : (int64_t)hs->hits.size(); }
+const prb_hit *prb_hitset_hits(const prb_hitset *hs) { return !hs ? nullptr : hs->ext_hits ? hs->ext_hits : hs->hits.data(); }
 const int32_t *prb_hitset_basepairs(const prb_hitset *hs, int64_t *count) {
   if (!hs) return nullptr;
-  if (count) *count = (int64_t)hs->bp.size() / 2;
-  return hs->bp.data();
+  if (count) *count = (hs->ext_hits ? hs->ext_bp_ints : (int64_t)hs->bp.size()) / 2;
+  return hs->ext_hits ? hs->ext_bp : hs->bp.data();
 }
 void prb_hitset_counts(const prb_hitset *hs, int64_t counts[3]) {
   for (int i = 0; i < 3; i++) counts[i] = hs ? hs->counts[i] : 0;

@@ -2,23 +2,38 @@
 //
 // Command line, defaults, error texts and the output format follow the reference
 // (main.cpp:36-111, 148-175; rna_interaction_search_parameters.cpp:33-114;
-// rna_interaction_search.cpp:322-369, 445-476).  `-a` and `-p` are accepted and ignored: the
-// MPI/OpenMP query schedulers are replaced by batched GPU stages; queries are dealt in
-// batches to the GPUs named by PRB_DEVICES (default: device 0).
+// rna_interaction_search.cpp:322-369, 445-476).  `-a` is accepted and ignored: the MPI/OpenMP query
+// schedulers are replaced by batched GPU stages.  Queries are sorted by length, longest first, as the
+// reference does before dealing them (utils.cpp:56-63, rna_interaction_search.cpp:145-153), cut into
+// batches of PRB_BATCH, and
+//   * one process: dealt from a counter to the workers named by PRB_DEVICES (default: device 0), one
+//     host thread each; a worker computes the accessibilities of its next batch under a second
+//     context while the current batch is searched; one writer thread prints finished batches in order;
+//   * one process per GPU (WORLD_SIZE / RANK / LOCAL_RANK in the environment, as torchrun or mpirun
+//     set them): batch b goes to rank b mod WORLD_SIZE, and after every round of batches the final
+//     hits are gathered on rank 0 over RCCL (prb_gather_hits), which writes the lines - the
+//     replacement of the reference's MPI token ring (rna_interaction_search.cpp:426-487).  The 128-byte
+//     RCCL id travels through a file in the `-p` temporary directory (default: next to the output).
 //
 // Two additions to the reference's surface (the output path): `ris -b` writes
 // the hits as binary records instead of text (no number formatting on the search path), and the
 // `txt` sub-command turns such a file into exactly the text `ris` would have written.
 #include <getopt.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <numeric>
 #include <condition_variable>
 #include <map>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -63,11 +78,12 @@ void usage() {
             "    -p STR    accepted for compatibility; ignored\n"
             "    -b        write binary hit records instead of text; `pRIblast-hip txt -i FILE -o TEXT` converts\n"
             "\n"
-            "  Environment: PRB_DEVICES=0,1,..  GPUs to use;  PRB_BATCH=N  queries per batch [default 2048]");
+            "  Environment: PRB_DEVICES=0,1,..  GPUs (workers) of this process;  PRB_BATCH=N  queries per batch [default 2048];\n"
+            "               WORLD_SIZE / RANK / LOCAL_RANK  one process per GPU, final hits gathered on rank 0 over RCCL");
 }
 
 struct Args {
-  std::string in, out, db;
+  std::string in, out, db, tmp;
   prb_ris_opts o;
   bool binary = false;
 };
@@ -79,15 +95,21 @@ struct Args {
 
 struct Worker {
   int device;
-  prb_ctx *ctx = nullptr;
+  prb_ctx *ctx = nullptr, *prep_ctx = nullptr; // prep_ctx: accessibilities of the next batch, on a stream of its own
   prb_db *db = nullptr;
 };
 
 // The hit sets of one batch (one per database page), waiting to be written.
 struct BatchJob {
-  size_t index = 0, b0 = 0, nq = 0;
-  Worker *w = nullptr;
+  size_t index = 0, nq = 0;
   std::vector<prb_hitset *> pages;
+  std::vector<std::string> names; // of its queries, in the order of their indices in the hit records
+  std::vector<int32_t> qlen_unmasked;
+};
+
+// A batch with its accessibilities computed, ready to be searched.
+struct Prepared {
+  prb_qbatch *qb = nullptr;
   std::vector<int32_t> qlen_unmasked;
 };
 
@@ -244,29 +266,59 @@ int txt_main(int argc, char **argv) {
   return 0;
 }
 
-// One batch through the GPU stages; the hit sets go to the writer.
-void run_batch(Worker &w, const Args &a, const std::vector<std::string> &seqs, size_t b0, size_t b1, int W, int delta,
-               int repeat_flag, int npages, BatchJob &job) {
+// encode + suffix arrays + accessibilities of the queries `idx` under context c
+Prepared prepare_batch(prb_ctx *c, const std::vector<std::string> &seqs, const std::vector<size_t> &idx, int W, int delta,
+                       int repeat_flag) {
   std::string cat;
-  std::vector<int64_t> off(b1 - b0 + 1, 0);
-  for (size_t i = b0; i < b1; i++) {
-    cat += seqs[i];
-    off[i - b0 + 1] = (int64_t)cat.size();
+  std::vector<int64_t> off(idx.size() + 1, 0);
+  for (size_t k = 0; k < idx.size(); k++) {
+    cat += seqs[idx[k]];
+    off[k + 1] = (int64_t)cat.size();
   }
-  prb_qbatch *qb = nullptr;
-  if (prb_qbatch_create(w.ctx, (int32_t)(b1 - b0), cat.data(), off.data(), repeat_flag, &qb)) die(prb_last_error());
-  if (prb_qbatch_accessibility(w.ctx, qb, W, delta)) die(prb_last_error());
-  job.b0 = b0;
-  job.nq = b1 - b0;
-  job.w = &w;
-  job.qlen_unmasked.resize(job.nq);
-  for (size_t q = 0; q < job.nq; q++) job.qlen_unmasked[q] = prb_qbatch_length_unmasked(qb, (int32_t)q);
+  Prepared p;
+  if (prb_qbatch_create(c, (int32_t)idx.size(), cat.data(), off.data(), repeat_flag, &p.qb)) die(prb_last_error());
+  if (prb_qbatch_accessibility(c, p.qb, W, delta)) die(prb_last_error());
+  p.qlen_unmasked.resize(idx.size());
+  for (size_t q = 0; q < idx.size(); q++) p.qlen_unmasked[q] = prb_qbatch_length_unmasked(p.qb, (int32_t)q);
+  return p;
+}
+
+// the search stages of a prepared batch against every page; the hit sets go to the writer
+void search_batch(Worker &w, const Args &a, Prepared &p, int npages, std::vector<prb_hitset *> &pages) {
   for (int page = 0; page < npages; page++) {
     prb_hitset *hs = nullptr;
-    if (prb_search_page(w.ctx, qb, w.db, page, &a.o, 3, &hs)) die(prb_last_error());
-    job.pages.push_back(hs);
+    if (prb_search_page(w.ctx, p.qb, w.db, page, &a.o, 3, &hs)) die(prb_last_error());
+    pages.push_back(hs);
   }
-  prb_qbatch_destroy(qb);
+  prb_qbatch_destroy(p.qb);
+  p.qb = nullptr;
+}
+
+// The RCCL id of a multi-process run: rank 0 writes it to `path` (atomically), the others wait for it.
+void exchange_comm_id(const std::string &path, int rank, char id[PRB_COMM_ID_BYTES]) {
+  if (rank == 0) {
+    if (prb_comm_unique_id(id)) die(std::string("Error: ") + prb_last_error());
+    const std::string tmp = path + ".tmp";
+    std::FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(id, 1, PRB_COMM_ID_BYTES, f) != PRB_COMM_ID_BYTES || std::fclose(f) || std::rename(tmp.c_str(), path.c_str()))
+      die("Error: can't write the rendezvous file " + path);
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const time_t started = std::time(nullptr);
+  for (;;) {
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && st.st_size == PRB_COMM_ID_BYTES && st.st_mtime + 120 >= started) { // (not a stale file of an earlier run)
+      std::FILE *f = std::fopen(path.c_str(), "rb");
+      if (f && std::fread(id, 1, PRB_COMM_ID_BYTES, f) == PRB_COMM_ID_BYTES) {
+        std::fclose(f);
+        return;
+      }
+      if (f) std::fclose(f);
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) die("Error: no rendezvous file " + path + " from rank 0");
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
 }
 
 int ris_main(int argc, char **argv) {
@@ -286,7 +338,7 @@ int ris_main(int argc, char **argv) {
     case 'x': a.o.drop_out_w_gap = std::atoi(optarg); break;
     case 'y': a.o.drop_out_wo_gap = std::atoi(optarg); break;
     case 'm': a.o.min_helix_length = std::atoi(optarg); break;
-    case 'p': break;
+    case 'p': a.tmp = optarg; break;
     case 'b': a.binary = true; break;
     case 'a':
       if (std::strcmp(optarg, "block") && std::strcmp(optarg, "area") && std::strcmp(optarg, "dynamic"))
@@ -307,14 +359,41 @@ int ris_main(int argc, char **argv) {
       if (*p == ',') p++;
     }
   }
+  // one process per GPU?  (torchrun / mpirun style environment)
+  auto env_int = [](const char *a, const char *b, int dflt) {
+    const char *e = std::getenv(a);
+    if (!e && b) e = std::getenv(b);
+    return e ? std::atoi(e) : dflt;
+  };
+  const int world = std::max(1, env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", 1));
+  const int rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", 0);
+  const bool rank_mode = world > 1 || std::getenv("PRB_FORCE_COMM") != nullptr;
+  if (rank < 0 || rank >= world) die("Error: RANK outside WORLD_SIZE");
+  if (rank_mode) {
+    const int local = env_int("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", rank);
+    const int dev = devices.empty() ? local : devices[(size_t)local % devices.size()];
+    devices.assign(1, dev);
+  }
   if (devices.empty()) devices.push_back(0);
   std::vector<Worker> workers(devices.size());
   int hash_size = 0, repeat_flag = 0, W = 0, delta = 0, npages = 0;
+  const bool prefetch = !std::getenv("PRB_NO_PREFETCH");
   for (size_t k = 0; k < devices.size(); k++) {
     workers[k].device = devices[k];
     if (prb_ctx_create(devices[k], nullptr, &workers[k].ctx)) die(std::string("Error: ") + prb_last_error());
+    if (prefetch && prb_ctx_create(devices[k], nullptr, &workers[k].prep_ctx)) die(std::string("Error: ") + prb_last_error());
     if (prb_db_open(workers[k].ctx, a.db.c_str(), &workers[k].db)) die(prb_last_error());
   }
+  prb_comm *comm = nullptr;
+  if (rank_mode) {
+    char id[PRB_COMM_ID_BYTES];
+    const char *port = std::getenv("MASTER_PORT");
+    const std::string path = (a.tmp.empty() ? a.out : a.tmp + "/prb") + ".rccl_id." + (port ? port : "0");
+    exchange_comm_id(path, rank, id);
+    if (prb_comm_create(workers[0].ctx, world, rank, id, &comm)) die(std::string("Error: ") + prb_last_error());
+    if (rank == 0) std::remove(path.c_str()); // every rank has read it: the communicator exists
+  }
+  const bool writer_rank = rank == 0;
   prb_db_info(workers[0].db, &hash_size, &repeat_flag, &W, &delta, &npages);
 
   std::vector<SeqTable> tabs((size_t)npages);
@@ -333,7 +412,7 @@ int ris_main(int argc, char **argv) {
     }
   }
 
-  std::FILE *out = std::fopen(a.out.c_str(), a.binary ? "wb" : "w");
+  std::FILE *out = std::fopen(writer_rank ? a.out.c_str() : "/dev/null", a.binary ? "wb" : "w");
   if (!out) die("Error: can't open output_file: " + a.out);
   // MergeOutput header, rna_interaction_search.cpp:445-463
   std::string header = "RIblast ris result\n";
@@ -358,11 +437,16 @@ int ris_main(int argc, char **argv) {
 
   const char *benv = std::getenv("PRB_BATCH");
   const size_t batch = std::max(1, benv ? std::atoi(benv) : 2048);
+  // longest first (stable: equal lengths keep their FASTA order), then batches in that order
+  std::vector<size_t> order(seqs.size());
+  std::iota(order.begin(), order.end(), (size_t)0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return seqs[x].size() > seqs[y].size(); });
   const size_t nb = (seqs.size() + batch - 1) / batch;
-  // GPU workers take batches from a counter; a writer thread turns finished batches into text in
-  // batch order while the GPUs already work on the next ones (at most two finished batches per
-  // worker wait for it).
-  std::atomic<size_t> next{0};
+  auto batch_idx = [&](size_t b) { return std::vector<size_t>(order.begin() + b * batch, order.begin() + std::min(seqs.size(), (b + 1) * batch)); };
+  // The writer thread turns finished jobs into text in job order while the GPUs already work on the
+  // next ones (a bounded number of finished jobs wait for it).  A job is a batch - or, with one process
+  // per GPU, a round of WORLD_SIZE batches gathered on rank 0.
+  const size_t njobs = rank_mode ? (nb + world - 1) / world : nb;
   std::mutex mu;
   std::condition_variable cv;
   std::map<size_t, BatchJob> done;
@@ -370,7 +454,7 @@ int ris_main(int argc, char **argv) {
   int64_t total_hits = 0;
   std::thread writer([&] {
     int64_t id = 0;
-    for (size_t b = 0; b < nb; b++) {
+    for (size_t b = 0; b < njobs && writer_rank; b++) {
       BatchJob job;
       {
         std::unique_lock<std::mutex> lk(mu);
@@ -380,7 +464,7 @@ int ris_main(int argc, char **argv) {
       }
       BatchView v;
       v.nq = job.nq;
-      v.names = names.data() + job.b0;
+      v.names = job.names.data();
       v.qlen_unmasked = job.qlen_unmasked.data();
       for (prb_hitset *hs : job.pages) {
         PageHits ph;
@@ -401,35 +485,112 @@ int ris_main(int argc, char **argv) {
     }
     total_hits = id;
   });
-  std::vector<std::thread> threads;
-  for (auto &w : workers)
-    threads.emplace_back([&, pw = &w] {
-      for (;;) {
-        const size_t b = next.fetch_add(1);
-        if (b >= nb) break;
-        {
-          std::unique_lock<std::mutex> lk(mu); // bound the hit sets held in memory
-          cv.wait(lk, [&] { return b < written + 2 * workers.size() + 1; });
-        }
-        BatchJob job;
-        job.index = b;
-        run_batch(*pw, a, seqs, b * batch, std::min(seqs.size(), (b + 1) * batch), W, delta, repeat_flag, npages, job);
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          done[b] = std::move(job);
-        }
-        cv.notify_all();
+  auto submit = [&](size_t index, BatchJob &&job) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      done[index] = std::move(job);
+    }
+    cv.notify_all();
+  };
+  auto names_of = [&](const std::vector<size_t> &idx, std::vector<std::string> &dst) {
+    for (size_t i : idx) dst.push_back(names[i]);
+  };
+  // A worker: its batches one after the other; the accessibilities of the next one are computed by a
+  // helper thread under the worker's second context while this one is searched.
+  auto work = [&](Worker &w, const std::function<bool(size_t &)> &next_batch, const std::function<void(size_t, Prepared *, std::vector<prb_hitset *> &)> &finish) {
+    size_t b = 0, bn = 0;
+    bool have = next_batch(b);
+    Prepared cur;
+    if (have) cur = prepare_batch(w.prep_ctx ? w.prep_ctx : w.ctx, seqs, batch_idx(b), W, delta, repeat_flag);
+    while (have) {
+      const bool more = next_batch(bn);
+      Prepared nxt;
+      std::thread helper;
+      if (more && w.prep_ctx) helper = std::thread([&] { nxt = prepare_batch(w.prep_ctx, seqs, batch_idx(bn), W, delta, repeat_flag); });
+      std::vector<prb_hitset *> pages;
+      search_batch(w, a, cur, npages, pages);
+      finish(b, &cur, pages);
+      if (helper.joinable()) helper.join();
+      else if (more) nxt = prepare_batch(w.ctx, seqs, batch_idx(bn), W, delta, repeat_flag);
+      cur = std::move(nxt);
+      b = bn;
+      have = more;
+    }
+  };
+  if (!rank_mode) {
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> threads;
+    for (auto &w : workers)
+      threads.emplace_back([&, pw = &w] {
+        work(*pw,
+             [&](size_t &b) {
+               b = next.fetch_add(1);
+               return b < nb;
+             },
+             [&](size_t b, Prepared *p, std::vector<prb_hitset *> &pages) {
+               {
+                 std::unique_lock<std::mutex> lk(mu); // bound the hit sets held in memory
+                 cv.wait(lk, [&] { return b < written + 2 * workers.size() + 1; });
+               }
+               BatchJob job;
+               job.index = b;
+               job.pages = pages;
+               job.qlen_unmasked = p->qlen_unmasked;
+               names_of(batch_idx(b), job.names);
+               job.nq = job.names.size();
+               submit(b, std::move(job));
+             });
+      });
+    for (auto &t : threads) t.join();
+  } else {
+    // round t: batch t * world + rank; every rank takes part in every round's gather, with or without a batch
+    size_t t_next = 0;
+    auto gather_round = [&](size_t t, Prepared *p, std::vector<prb_hitset *> &pages) {
+      BatchJob job;
+      job.index = t;
+      for (int page = 0; page < npages; page++) {
+        prb_hitset *mine = pages.empty() ? nullptr : pages[(size_t)page], *all = nullptr;
+        if (prb_gather_hits(comm, mine, p ? (int32_t)p->qlen_unmasked.size() : 0, p ? p->qlen_unmasked.data() : nullptr, 0, &all))
+          die(std::string("Error: ") + prb_last_error());
+        if (mine) prb_hitset_free(mine);
+        if (all) job.pages.push_back(all);
       }
-    });
-  for (auto &t : threads) t.join();
+      if (!writer_rank) return;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return t < written + 3; });
+      }
+      int32_t nr = 0;
+      const int32_t *nq_of = nullptr, *ql = nullptr;
+      if (!job.pages.empty() && prb_hitset_gathered_queries(job.pages[0], &nr, &nq_of, &ql)) die(std::string("Error: ") + prb_last_error());
+      for (int r = 0; r < nr; r++)
+        if (nq_of[r]) names_of(batch_idx(t * (size_t)world + (size_t)r), job.names);
+      job.nq = job.names.size();
+      job.qlen_unmasked.assign(ql, ql + job.nq);
+      submit(t, std::move(job));
+    };
+    work(workers[0],
+         [&](size_t &b) {
+           b = t_next * (size_t)world + (size_t)rank;
+           t_next++;
+           return b < nb;
+         },
+         [&](size_t b, Prepared *p, std::vector<prb_hitset *> &pages) { gather_round(b / (size_t)world, p, pages); });
+    // rounds in which this rank has no batch left (the last one, when nb is not a multiple of world)
+    const size_t mine_rounds = nb > (size_t)rank ? (nb - (size_t)rank + (size_t)world - 1) / (size_t)world : 0;
+    std::vector<prb_hitset *> none;
+    for (size_t t = mine_rounds; t < njobs; t++) gather_round(t, nullptr, none);
+  }
   writer.join();
   if (a.binary) {
     put<int64_t>(out, kEnd);
     put<int64_t>(out, total_hits);
   }
   if (std::fclose(out)) die("Error: can't write the output file");
+  if (comm) prb_comm_destroy(comm);
   for (auto &w : workers) {
     prb_db_close(w.db);
+    if (w.prep_ctx) prb_ctx_destroy(w.prep_ctx);
     prb_ctx_destroy(w.ctx);
   }
   return 0;

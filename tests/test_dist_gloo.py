@@ -1,5 +1,7 @@
-"""world_size-2 test (gloo, CPU) of the multi-process plumbing used by bench.py for N > 1:
-disjoint query batches per rank and the variable-length final hit gather."""
+"""world_size-2 test (gloo, CPU) of the multi-process plumbing used for N > 1: disjoint query batches per
+rank, and the semantics of the final hit gather (prb_gather_hits; here its host statement
+priblast_amd.dist.gather_batch_host): hits AND base pairs of every rank on the root, `query` and
+`bp_offset` rebased, so that the root can print every result line."""
 import os
 import tempfile
 import sys
@@ -10,38 +12,58 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _lines(hits, bp, names):
+    """result lines as SaveMyResults prints them (-s 1), from hit records + their pair array"""
+    out = []
+    for h in hits:
+        pp = bp[h["bp_offset"]:h["bp_offset"] + h["bp_count"]]
+        out.append(f"{names[h['query']]},{h['q_sp']},{h['db_sp']},{'%g' % h['e_tot']}," + "".join(f"({a}:{b}) " for a, b in pp))
+    return out
+
+
+def _make(rank, capi):
+    """ragged batches, an empty one included: rank 0 has 3 queries / 7 hits, rank 1 has 2 queries / 0 or 5 hits"""
+    rng = np.random.default_rng(100 + rank)
+    nq = 3 if rank == 0 else 2
+    n = 7 if rank == 0 else 5
+    hits = np.zeros(n, capi.HIT_DTYPE)
+    hits["query"] = np.sort(rng.integers(0, nq, n))
+    hits["q_sp"] = rng.integers(0, 100, n)
+    hits["db_sp"] = rng.integers(0, 1000, n)
+    hits["e_tot"] = -8.5 - rng.random(n)
+    hits["bp_count"] = rng.integers(1, 6, n)
+    hits["bp_offset"] = np.concatenate([[0], np.cumsum(hits["bp_count"])[:-1]])
+    bp = rng.integers(0, 1000, (int(hits["bp_count"].sum()), 2)).astype(np.int32)
+    names = [f"r{rank}q{i}" for i in range(nq)]
+    qlen = [100 * rank + i for i in range(nq)]
+    return hits, bp, names, qlen
+
+
 def _worker(rank, world, store, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from priblast_amd import capi, dist as pdist
     dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
     try:
-        per_step = 5
-        covered = []
-        for step in range(3):
-            lo, hi = pdist.batch_slice(step, rank, world, per_step)
-            covered.append((lo, hi))
-        n = 7 if rank == 0 else 0  # ragged, including an empty rank
-        hits = np.zeros(n, capi.HIT_DTYPE)
-        hits["q_sp"] = np.arange(n) + 100 * rank
-        hits["e_tot"] = -8.5 - rank
-        hits["query"] = rank
-        got = pdist.gather_hits(hits)
-        got_list = got.tolist() if rank == 0 else None  # the result is a view of a buffer the next gather reuses
-        n2 = 3 + rank
-        h2 = np.zeros(n2, capi.HIT_DTYPE)
-        h2["db_sp"] = 1000 * rank + np.arange(n2)
-        got2 = pdist.gather_hits(h2)
+        covered = [pdist.batch_slice(step, rank, world, 5) for step in range(3)]
+        hits, bp, names, qlen = _make(rank, capi)
+        got = pdist.gather_batch_host(hits, bp, qlen)
+        # a second round in which rank 1 has nothing at all
+        e = (hits[:0], bp[:0], []) if rank == 1 else (hits, bp, qlen)
+        got2 = pdist.gather_batch_host(*e)
         if rank == 0:
-            q.put((covered, got_list, got2["db_sp"].tolist()))
+            all_names = [n for r in range(world) for n in _make(r, capi)[2]]
+            q.put((covered, _lines(got[0], got[1], all_names), got[2].tolist(), got[3].tolist(), len(got2[0]), got2[2].tolist()))
         else:
             assert got is None and got2 is None
-            q.put((covered, None, None))
+            q.put((covered, None, None, None, None, None))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_rank_sharding_and_gather():
+    sys.path.insert(0, ROOT)
+    from priblast_amd import capi
     store = os.path.join(tempfile.mkdtemp(prefix="prb_gloo_"), "rendezvous")
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
@@ -56,5 +78,18 @@ def test_two_rank_sharding_and_gather():
     # the ranks' batches tile the query range without overlap
     assert slices == [(k * 5, k * 5 + 5) for k in range(6)]
     root = [r for r in res if r[1] is not None][0]
-    assert len(root[1]) == 7 and [h[0] for h in root[1]] == list(range(7))
-    assert root[2] == [0, 1, 2, 1000, 1001, 1002, 1003]
+    # the root prints exactly the lines every rank would have printed on its own, in rank order
+    want = []
+    for r in range(2):
+        hits, bp, names, _ = _make(r, capi)
+        want += _lines(hits, bp, names)
+    assert root[1] == want
+    assert root[2] == [3, 2] and root[3] == [0, 1, 2, 100, 101]
+    assert root[4] == 7 and root[5] == [3, 0]
+
+
+def test_longest_first_dealing():
+    sys.path.insert(0, ROOT)
+    from priblast_amd import dist as pdist
+    lens = [5, 9, 9, 1, 7, 9, 3]
+    assert pdist.deal_longest_first(lens, 3) == [[1, 2, 5], [4, 0, 6], [3]]

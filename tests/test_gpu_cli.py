@@ -67,3 +67,86 @@ def test_binary_output_converts_to_the_same_text(golden_dir, tmp_path, style):
     with open(txt, "rb") as f, open(back, "rb") as g:
         a, b = f.read(), g.read()
     assert a.count(b"\n") > 10 and a == b
+
+
+def _run_ris(tmp_path, golden_dir, name, env_extra, style=1, extra=()):
+    from priblast_amd import capi
+    out = str(tmp_path / name)
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    subprocess.run([capi.BIN_PATH, "ris", "-i", os.path.join(GOLDEN, "mix_q.fa"), "-o", out, "-d", os.path.join(golden_dir, "mixdb"),
+                    "-s", str(style)] + list(extra), check=True, env=env)
+    with open(out, "rb") as f:
+        return f.read()
+
+
+def test_two_workers_write_the_same_file(golden_dir, tmp_path):
+    """PRB_DEVICES=0,0: two workers (host threads, each with its own contexts) take batches from the counter,
+    finish out of order, one writer - the output must be the file one worker writes, byte for byte;
+    likewise without the prefetch of the next batch's accessibilities."""
+    one = _run_ris(tmp_path, golden_dir, "one.txt", {"PRB_BATCH": "3"})
+    two = _run_ris(tmp_path, golden_dir, "two.txt", {"PRB_BATCH": "3", "PRB_DEVICES": "0,0"})
+    plain = _run_ris(tmp_path, golden_dir, "plain.txt", {"PRB_BATCH": "3", "PRB_NO_PREFETCH": "1"})
+    assert one.count(b"\n") > 10
+    assert one == two and one == plain
+
+
+def test_batches_are_dealt_longest_first(golden_dir, tmp_path):
+    """mixed lengths: the queries come out in batch order = by descending length (ties in FASTA order)"""
+    import refdump
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    body = _run_ris(tmp_path, golden_dir, "o.txt", {"PRB_BATCH": "2"}, style=0).decode().splitlines()[3:]
+    seen = []
+    for line in body:
+        q = line.split(",")[1]
+        if not seen or seen[-1] != q:
+            seen.append(q)
+    order = sorted(range(len(seqs)), key=lambda i: -len(seqs[i]))
+    assert seen == [names[i] for i in order if names[i] in set(seen)]
+    assert len(set(seen)) == len(seen)
+
+
+def test_rank_mode_gathers_over_rccl(golden_dir, tmp_path):
+    """One process per GPU, here a world of one (the box has one GPU): the whole rank-mode path - RCCL id
+    through the rendezvous file, communicator, device-resident records, prb_gather_hits per round and
+    page, rank 0 writing the gathered hits - must give the file the plain run writes."""
+    plain = _run_ris(tmp_path, golden_dir, "plain.txt", {"PRB_BATCH": "3"})
+    (tmp_path / "tmpdir").mkdir()
+    ranked = _run_ris(tmp_path, golden_dir, "ranked.txt", {"PRB_BATCH": "3", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+                                                            "MASTER_PORT": "29517", "PRB_FORCE_COMM": "1"},
+                      extra=["-p", str(tmp_path / "tmpdir")])
+    assert plain == ranked
+    assert not list((tmp_path / "tmpdir").iterdir())  # the rendezvous file is gone
+
+
+def test_native_gather_matches_the_host_statement(golden_dir):
+    """prb_gather_hits with a communicator of one rank: the gathered hit set (device-resident records ->
+    RCCL path -> pinned memory) equals the hit set itself, for every page, -s 0 and -s 1."""
+    import numpy as np
+    import refdump
+    from priblast_amd import capi
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    with capi.Context(0) as ctx:
+        comm = capi.Comm(ctx, 1, 0, capi.Comm.unique_id())
+        db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+        qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+        qb.accessibility(db.W, db.delta)
+        qlen = [qb.length_unmasked(q) for q in range(len(seqs))]
+        total = 0
+        for style in (0, 1):
+            for page in range(db.npages):
+                hs = capi.search_page_hs(ctx, qb, db, page, capi.default_opts(output_style=style))
+                g, nq_of, qall = comm.gather(hs, qlen)
+                assert np.array_equal(g.hits, hs.hits) and np.array_equal(g.bp, hs.bp)
+                assert nq_of.tolist() == [len(seqs)] and qall.tolist() == qlen
+                total += len(hs.hits)
+                del g
+        assert total > 0
+        g, nq_of, qall = comm.gather(None, [])  # a rank without a batch
+        assert len(g.hits) == 0 and nq_of.tolist() == [0]
+        del g
+        qb.close()
+        db.close()
+        comm.close()

@@ -139,29 +139,48 @@ def test_results_do_not_depend_on_batch_composition(ctx, golden_dir, monkeypatch
 
 
 _GATHER_SCRIPT = """
-import sys
+import gzip, os, shutil, sys, tempfile
 import numpy as np
 import torch
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[2])
+sys.path.insert(0, os.path.join(sys.argv[2], "tests"))
+import refdump
 from priblast_amd import capi, dist as pdist
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="file://" + sys.argv[1], rank=0, world_size=1, device_id=torch.device("cuda", 0))
-hits = np.zeros(300_000, capi.HIT_DTYPE)
-hits["q_sp"] = np.arange(len(hits))
-hits["e_tot"] = -8.0 - np.arange(len(hits)) * 1e-6
-got = pdist.gather_hits(hits, 0, "cuda")
-assert got.dtype == capi.HIT_DTYPE and np.array_equal(got, hits)
-assert len(pdist.gather_hits(hits[:0], 0, "cuda")) == 0
+golden = os.path.join(sys.argv[2], "tests", "golden")
+tmp = tempfile.mkdtemp()
+for ext in ("bas", "seq", "acc", "nam", "ind"):
+    with gzip.open(os.path.join(golden, f"c1db.{ext}.gz"), "rb") as f, open(os.path.join(tmp, f"c1db.{ext}"), "wb") as g:
+        shutil.copyfileobj(f, g)
+names, seqs = refdump.read_fasta(os.path.join(golden, "c1_q.fa"))
+ctx = capi.Context(0)
+comm = pdist.NativeComm(ctx, 0, 1)  # the RCCL id through torch.distributed, the communicator in the library
+db = capi.Db(ctx, os.path.join(tmp, "c1db"))
+qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+qb.accessibility(db.W, db.delta)
+qlen = [qb.length_unmasked(q) for q in range(len(seqs))]
+sets = [capi.search_page_hs(ctx, qb, db, p) for p in range(db.npages)]
+pages, nq_of, qall = comm.gather_batch(sets, qlen)
+assert len(pages) == db.npages and sum(len(h) for h, _ in pages) > 100
+for (h, b), hs in zip(pages, sets):
+    assert np.array_equal(h, hs.hits) and np.array_equal(b, hs.bp)
+assert nq_of.tolist() == [len(seqs)] and qall.tolist() == qlen
+lines, nbytes = capi.write_lines(db, names, qall, pages, 0, 0, -1)  # the root can print every line
+assert lines == sum(len(h) for h, _ in pages) and nbytes > 50 * lines
+del pages, sets
+qb.close(); db.close(); comm.close(); ctx.close()
 dist.destroy_process_group()
 print("gather ok")
 """
 
 
 def test_final_gather_on_the_gpu_backend(tmp_path):
-    """The RCCL path of the final hit gather (device buffers, pinned root buffer) with the one rank
-    this box has, in a process of its own (torch has to initialise the GPU before the library
-    does); the two-rank logic is covered on CPU by tests/test_dist_gloo.py."""
+    """bench.py's N > 1 path with the one rank this box has, in a process of its own (torch initialises the
+    GPU and loads its own RCCL first): torch.distributed carries the RCCL id, the library's communicator
+    gathers the device-resident records, the root formats every line.  The two-rank semantics are covered
+    on CPU by tests/test_dist_gloo.py."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
