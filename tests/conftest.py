@@ -28,7 +28,7 @@ def _unpack_db(tag, dst):
 def golden_dir(tmp_path_factory):
     """tests/golden with the gzip'd reference-built DBs and stage dumps unpacked."""
     d = tmp_path_factory.mktemp("golden")
-    for tag in ("c1", "mix"):
+    for tag in ("c1", "mix", "quirk"):
         _unpack_db(tag, str(d))
     return str(d)
 

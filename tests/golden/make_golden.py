@@ -14,6 +14,10 @@ compiled reference produced for them (strict build: -ffp-contract=off, SURVEY.md
   mix_*.fa, mixdb.*.gz, mix_ris_s{0,1}.out, mix.stg.gz
                         mixed-length case: N / lowercase, 3 DB pages (-c 10)
   c1_q.sa               encoder + suffix array goldens             (ref_harness sa)
+  quirk_*.fa, quirkdb.*.gz, quirk_ris_s{0,1}.out, quirk.stg.gz
+                        designed duplexes with a bulge next to the seed: the FIRST post-ungapped hit of a
+                        query is gapped-extended and survives the final filter, so it keeps the unsorted
+                        base-pair order of rna_interaction_search.cpp:314-317; 5 DB pages
 """
 import gzip
 import os
@@ -105,27 +109,59 @@ def mix_inputs():
     return q, db
 
 
+def quirk_inputs():
+    """Queries X+Y (or Y+X) in poly-A, targets rc(Y)+bulge+rc(X) in poly-C: the seed covers one arm, the
+    ungapped extension stops at the bulge, the gapped extension crosses it.  The designs (seeds 1, 2, 3, 5, 8 of
+    the generator below) were picked with `ref_harness stages`: each gives a final hit whose stored pairs are
+    [diagonal, left chain, right chain outer->inner], i.e. not ascending."""
+    comp = {"A": "U", "C": "G", "G": "C", "U": "A"}
+
+    def rc(x):
+        return "".join(comp[c] for c in reversed(x))
+    q, db = [], []
+    for k, seed in enumerate((1, 2, 3, 5, 8)):
+        rng = random.Random(seed)
+        X = "".join(rng.choice("GC" if rng.random() < 0.6 else "AU") for _ in range(rng.randint(8, 12)))
+        Y = "".join(rng.choice("GC" if rng.random() < 0.6 else "AU") for _ in range(rng.randint(5, 9)))
+        bulge = "".join(rng.choice("AC") for _ in range(rng.randint(1, 2)))
+        side = rng.random() < 0.5
+        q.append((f"kq{k}", "A" * 25 + (X + Y if side else Y + X) + "A" * 25))
+        db.append((f"kd{k}", "C" * 20 + (rc(Y) + bulge + rc(X) if side else rc(X) + bulge + rc(Y)) + "C" * 20))
+        db.append((f"kdecoy{k}", "".join(rng.choice("ACGU") for _ in range(120))))
+    rng = random.Random(99)
+    q.append(("kq_random", "".join(rng.choice("ACGU") for _ in range(150))))
+    return q, db
+
+
 def main():
     assert os.path.exists(os.path.join(REF, "ref_harness")), "run `make -C oracle ref` first"
     strict = os.path.join(REF, "pRIblast.strict")
     harness = os.path.join(REF, "ref_harness")
     tmp = tempfile.mkdtemp(prefix="golden_")
+    only = set(sys.argv[1:])  # e.g. `make_golden.py quirk`: only the ris cases named
 
-    run(harness, "tables", os.path.join(HERE, "tables.bin"))
+    if not only:
+        run(harness, "tables", os.path.join(HERE, "tables.bin"))
 
-    gen_synthetic.write_fasta(os.path.join(HERE, "corpus.fa"), corpus())
-    run(harness, "raccess", os.path.join(HERE, "corpus.fa"), "70", "5", os.path.join(HERE, "corpus.racc"))
+        gen_synthetic.write_fasta(os.path.join(HERE, "corpus.fa"), corpus())
+        run(harness, "raccess", os.path.join(HERE, "corpus.fa"), "70", "5", os.path.join(HERE, "corpus.racc"))
 
-    # ---- config 1 ----
-    gen_synthetic.write_fasta(os.path.join(HERE, "c1_db.fa"), gen_synthetic.gen(32, 200, 1, "db"))
-    gen_synthetic.write_fasta(os.path.join(HERE, "c1_q.fa"), gen_synthetic.gen(32, 200, 2, "q"))
-    # a second (W, delta) so the band geometry is not hard-wired to the defaults
-    run(harness, "raccess", os.path.join(HERE, "c1_q.fa"), "40", "7", os.path.join(HERE, "c1_q_w40d7.racc"))
-    run(harness, "sa", os.path.join(HERE, "c1_q.fa"), "0", os.path.join(HERE, "c1_q.sa"))
-    cases = [("c1", "c1_q.fa", "c1_db.fa", []), ("mix", "mix_q.fa", "mix_db.fa", ["-c", "10"])]
+        # ---- config 1 ----
+        gen_synthetic.write_fasta(os.path.join(HERE, "c1_db.fa"), gen_synthetic.gen(32, 200, 1, "db"))
+        gen_synthetic.write_fasta(os.path.join(HERE, "c1_q.fa"), gen_synthetic.gen(32, 200, 2, "q"))
+        # a second (W, delta) so the band geometry is not hard-wired to the defaults
+        run(harness, "raccess", os.path.join(HERE, "c1_q.fa"), "40", "7", os.path.join(HERE, "c1_q_w40d7.racc"))
+        run(harness, "sa", os.path.join(HERE, "c1_q.fa"), "0", os.path.join(HERE, "c1_q.sa"))
+    cases = [("c1", "c1_q.fa", "c1_db.fa", []), ("mix", "mix_q.fa", "mix_db.fa", ["-c", "10"]),
+             ("quirk", "quirk_q.fa", "quirk_db.fa", ["-c", "2"])]
+    if only:
+        cases = [c for c in cases if c[0] in only]
     mq, mdb = mix_inputs()
     gen_synthetic.write_fasta(os.path.join(HERE, "mix_q.fa"), mq)
     gen_synthetic.write_fasta(os.path.join(HERE, "mix_db.fa"), mdb)
+    kq, kdb = quirk_inputs()
+    gen_synthetic.write_fasta(os.path.join(HERE, "quirk_q.fa"), kq)
+    gen_synthetic.write_fasta(os.path.join(HERE, "quirk_db.fa"), kdb)
     for tag, qfa, dbfa, dbopts in cases:
         dbp = os.path.join(tmp, tag + "db")
         run(strict, "db", "-i", os.path.join(HERE, dbfa), "-o", dbp, *dbopts, cwd=tmp)

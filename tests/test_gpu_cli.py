@@ -16,7 +16,7 @@ def body(path):
     return lines[:3], sorted(l.split(",", 1)[1] for l in lines[3:])
 
 
-@pytest.mark.parametrize("tag", ["c1", "mix"])
+@pytest.mark.parametrize("tag", ["c1", "mix", "quirk"])
 @pytest.mark.parametrize("style", [0, 1])
 def test_ris_cli_matches_reference(golden_dir, tmp_path, tag, style):
     from priblast_amd import capi

@@ -52,7 +52,7 @@ def same(a, b, split_tol=0.0, with_bp=True):
     return (not with_bp) or np.array_equal(a["bp"], b["bp"])
 
 
-@pytest.mark.parametrize("tag", ["c1", "mix"])
+@pytest.mark.parametrize("tag", ["c1", "mix", "quirk"])
 def test_stage_dumps(ctx, golden_dir, tag):
     from priblast_amd import capi
     names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
@@ -126,7 +126,7 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     instead of the one-key sort + tie pass."""
     from priblast_amd import capi
     env, _, value = env.partition("=")
-    for tag in ("c1", "mix"):
+    for tag in ("c1", "mix", "quirk"):
         names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
         db = capi.Db(ctx, os.path.join(golden_dir, f"{tag}db"))
         qb = capi.QBatch(ctx, seqs, db.repeat_flag)

@@ -48,7 +48,7 @@ def test_encoder_repeat_flags(lib):
 
 def test_suffix_array_page_text(lib, golden_dir):
     """Page texts contain many sentinels (one per sequence): compare with the SA the reference stored."""
-    for tag in ("c1", "mix"):
+    for tag in ("c1", "mix", "quirk"):
         seq = np.fromfile(os.path.join(golden_dir, f"{tag}db.seq"), dtype=np.uint8)
         ind = np.fromfile(os.path.join(golden_dir, f"{tag}db.ind"), dtype="<i4")
         nseq = int(seq[:4].view("<i4")[0])
@@ -282,3 +282,15 @@ def test_txt_converter_prints_like_the_reference_stream(lib, tmp_path):
             want.append(f"{k},{qnames[h['query']]},{qlen[h['query']]},{dnames[d]},{dlen[d] - 1},"
                         f"{'%g' % h['e_acc']},{'%g' % h['e_hyb']},{'%g' % h['e_tot']},{pairs}\n")
         assert dst.read_text() == "".join(want)
+
+
+def test_fast_generator_replays_the_seeded_python_stream():
+    """tools/gen_synthetic.gen_fixed (numpy replay of the Mersenne Twister stream) = gen (random.Random(seed)
+    .choice per base, the definition of the synthetic inputs in BASELINE.md), across chunk boundaries too."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic
+    for seed, n, L in ((1, 40, 333), (2, 7, 2000), (12345, 3, 1)):
+        assert gen_synthetic.gen_fixed(n, L, seed, "x") == list(gen_synthetic.gen(n, L, seed, "x"))
+    arr = gen_synthetic._fixed_fast(30, 500, 2, "ACGU")  # the fast path itself, not its fallback
+    assert [r.tobytes().decode() for r in arr] == [s for _, s in gen_synthetic.gen(30, 500, 2, "q")]

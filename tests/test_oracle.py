@@ -106,7 +106,7 @@ def _same_hit(a, b, split_tol=0.0):
     return np.array_equal(a["bp"], b["bp"])
 
 
-@pytest.mark.parametrize("tag", ["c1", "mix"])
+@pytest.mark.parametrize("tag", ["c1", "mix", "quirk"])
 def test_stage_dumps(oracle, golden_dir, tag):
     """Per-stage parity: seed hits in the reference's emission order; post-extension lists as
     multisets (the reference's std::sort leaves ties of its comparator unordered)."""
@@ -134,7 +134,7 @@ def test_stage_dumps(oracle, golden_dir, tag):
         assert (nseed, nung, ngap) == (42110, 6352, 127)
 
 
-@pytest.mark.parametrize("tag", ["c1", "mix"])
+@pytest.mark.parametrize("tag", ["c1", "mix", "quirk"])
 @pytest.mark.parametrize("style", [0, 1])
 def test_ris_output_matches_reference(oracle, golden_dir, tmp_path, tag, style):
     out = str(tmp_path / "o.out")
@@ -148,3 +148,25 @@ def test_ris_output_matches_reference(oracle, golden_dir, tmp_path, tag, style):
     body = oracle.sorted_body(out)
     assert n == len(body) == len(gold) - 2
     assert body == gold[2:]
+
+
+def test_quirk_fixture_holds_unsorted_final_hits(oracle, golden_dir):
+    """The point of the `quirk` case (rna_interaction_search.cpp:314-317): final hits of the
+    REFERENCE whose stored base pairs are not ascending - hit 0 of a (query, page) list keeps
+    [diagonal, left chain, right chain outer->inner] - with a left and a right extension among them, and the
+    restatement reproduces each of them pair for pair (test_stage_dumps compares the lists in order)."""
+    stg = refdump.read_stages(os.path.join(golden_dir, "quirk.stg"))
+    shapes = set()
+    for rec in stg:
+        for h in rec["gapped"]:
+            q = [int(p[0]) for p in h["bp"]]
+            if q != sorted(q):
+                shapes.add("right" if q[-1] < max(q) and q[0] == min(q) else "left")
+    assert shapes == {"left", "right"}
+    with open(os.path.join(GOLDEN, "quirk_ris_s1.out")) as f:
+        body = f.read().splitlines()[2:]
+    unsorted_lines = 0
+    for line in body:
+        q = [int(t[1:].split(":")[0]) for t in line.split(",")[-1].split()]
+        unsorted_lines += q != sorted(q)
+    assert unsorted_lines >= 4
