@@ -46,12 +46,12 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, laneScratch;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &laneScratch})
       b->release();
     pinned.release();
     cand_pinned.release();
@@ -981,6 +981,23 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     int64_t m = nung;
     uint32_t *bufs[2] = {w.listA.as<uint32_t>(), w.listB.as<uint32_t>()};
     int nb = 0;
+    // In front of the cascade, on request (PRB_GAPPED_LANE; not faster yet, see gapped_lane.hip): a lane per hit for
+    // the extensions that stay small - most of them.  What it completes is reported as tier 0 (whose capacities
+    // cover it, should such a hit be re-extended for its pairs).
+    if (cascade[0] == 0 && getenv("PRB_GAPPED_LANE") && gapped_lane_supported(sc, eo)) {
+      if ((rc = w.laneScratch.ensure(gapped_lane_scratch_bytes()))) return rc;
+      if ((rc = ctx->time_begin())) return rc;
+      PRB_HIP(launch_gapped_lane(U, G, m, cur, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
+                                 w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), w.count.as<unsigned long long>() + 1,
+                                 w.laneScratch.p, ctx->stream));
+      int64_t rest = 0;
+      if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
+      cur = bufs[nb];
+      nb ^= 1;
+      ctx->timers["gapped_lane_hits"].launches += m - rest; // (a counter, not a time: hits completed by the lane kernel)
+      m = rest;
+      if ((rc = ctx->time_end("gapped_lane", 1))) return rc;
+    }
     for (size_t c = 0; c < cascade.size() && m > 0; c++) {
       const int tier = cascade[c];
       if ((rc = ctx->time_begin())) return rc;

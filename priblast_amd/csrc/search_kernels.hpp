@@ -185,6 +185,15 @@ constexpr int kTraceCap = 32;
 // ids of the gapped kernels a hit can be completed by (tier_out): LDS tiers 0..3, then the
 // wavefront-per-hit kernel with its state in HBM scratch
 constexpr int kLdsTiers = 4, kWaveTier = 4;
+// launch_gapped_lane (gapped_lane.hip): the first kernel of the cascade, a lane per hit, kLaneCapD anti-diagonals and
+// kLaneCapR filled cells per direction; hits that outgrow it are flagged in overflow[] (with direction 0
+// handed over when it was completed) and go on to the LDS tiers.  Completed hits are reported as `tier_id`.
+constexpr int kLaneCapD = 27, kLaneCapR = 24;
+size_t gapped_lane_scratch_bytes(); // HBM scratch of a launch (accessibility sums of the resident wavefronts)
+bool gapped_lane_supported(const SearchConst &sc, const ExtOpts &o);
+hipError_t launch_gapped_lane(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
+                              const SearchConst &sc, ExtOpts o, int tier_id, uint8_t *overflow, uint8_t *tier_out, int32_t *bp_count,
+                              uint16_t *trace, unsigned long long *next_work, void *scratch, hipStream_t s);
 hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                             const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
                             const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
