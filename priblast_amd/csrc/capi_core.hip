@@ -150,7 +150,9 @@ int prb_ctx_create(int device, const char *param_file, prb_ctx **out) {
   size_t free_b = 0, total_b = 0;
   PRB_HIP(hipMemGetInfo(&free_b, &total_b));
   const char *env = getenv("PRB_RACCESS_WORKSPACE_GB");
-  double gb = env ? atof(env) : 24.0;
+  // default: room for one sequence per resident wavefront at 2 kb (256 CUs x 12 wavefronts x 2,000 nt x 7.5 KB): a launch
+  // with fewer sequences than that is bound by the latency of one sequence, not by throughput
+  double gb = env ? atof(env) : 48.0;
   ctx->ra_budget_bytes = (size_t)std::min(gb * (double)(1ull << 30), 0.5 * (double)free_b);
   *out = ctx;
   return PRB_OK;

@@ -454,6 +454,9 @@ int prb_db_build(prb_ctx *ctx, const char *prefix, int32_t nseq, const char *con
       return PRB_ERR_IO;
     }
   }
+  // the band tables of a whole database build (tens of GB) are not what the query batches that follow need
+  ctx->ra_band.release();
+  ctx->ra_vec.release();
   return PRB_OK;
 }
 

@@ -120,6 +120,41 @@ __device__ __forceinline__ double ra_loop_energy(const RaLds &s, const double *_
   return z;
 }
 
+// The same loop energy without branches, for callers whose lanes look at loops of different classes (every
+// class would otherwise be walked through by the whole wavefront, each with its own table latency): one
+// look-up in the big table (1x1, 2x1, 1x2, 2x2 loops), four in the LDS table, and the class decides which of
+// them are added - in the order of the branches above, so the sum is bit-identical.
+__device__ __forceinline__ double ra_loop_energy_bf(const RaLds &s, const double *__restrict__ big, int type, int type2, int u1,
+                                                    int u2, int b_i1, int b_j1, int b_p1, int b_q1) {
+  using S = RaSmallLayout;
+  using B = RaBigLayout;
+  const bool z1 = u1 == 0, z2 = u2 == 0;
+  const bool stack = z1 && z2, bulge = z1 != z2;
+  const int u = z1 ? u2 : u1;
+  const bool c11 = u1 == 1 && u2 == 1, c12 = u1 == 1 && u2 == 2, c21 = u1 == 2 && u2 == 1, c22 = u1 == 2 && u2 == 2;
+  const bool special = c11 || c12 || c21 || c22;
+  const bool generic = !stack && !bulge && !special;
+  const int tt = type * 8 + type2;
+  int ib = B::kInt11 + (tt * 5 + b_i1) * 5 + b_j1;
+  if (c12) ib = B::kInt21 + ((tt * 5 + b_i1) * 5 + b_q1) * 5 + b_j1;
+  if (c21) ib = B::kInt21 + (((type2 * 8 + type) * 5 + b_q1) * 5 + b_i1) * 5 + b_p1;
+  if (c22) ib = B::kInt22 + (((tt * 5 + b_i1) * 5 + b_p1) * 5 + b_q1) * 5 + b_j1;
+  const double vb = big[ib]; // (always a valid index: unconditional, so that a batch of terms has its look-ups in flight together)
+  const int st = S::kStack + type * 7 + type2;
+  const int i1 = stack ? st : bulge ? S::kBulge + u : S::kInternal + u1 + u2;
+  const int i2 = bulge ? (u == 1 ? st : S::kTermAU) : S::kMismatchI + (type * 5 + b_i1) * 5 + b_j1;
+  const int i3 = bulge ? S::kTermAU : S::kMismatchI + (type2 * 5 + b_q1) * 5 + b_p1;
+  const int du = u1 - u2;
+  const double t1 = s.small[i1], t2 = s.small[i2], t3 = s.small[i3], t4 = s.small[S::kNinio + (du < 0 ? -du : du)];
+  const bool use2 = bulge ? (u == 1 || type > 2) : generic;
+  const bool use3 = bulge ? (u != 1 && type2 > 2) : generic;
+  double z = special ? vb : t1;
+  if (use2) z += t2;
+  if (use3) z += t3;
+  if (generic) z += t4;
+  return z;
+}
+
 // HairpinEnergy(type, i, j): d = j-i-1 unpaired, b_i1 = s[i+1], b_j1 = s[j-1].
 __device__ __forceinline__ double ra_hairpin_energy(const RaLds &s, int type, int d, int b_i1, int b_j1) {
   using S = RaSmallLayout;

@@ -23,6 +23,27 @@ namespace prb {
 
 namespace {
 
+// Developer-only cycle breakdown per phase (make prof; tools/raccess_profile.py): wave-cycles of the first
+// wavefront of a launch, accumulated by lane 0 at every phase boundary.  Not part of the product build.
+#ifdef PRB_GAP_PROFILE
+__device__ unsigned long long g_ra_prof[32];
+#define RA_COUNT(k, v)            \
+  do {                            \
+    if (ra_p_) g_ra_prof[k] += (v); \
+  } while (0)
+#define RA_PROF_DECL unsigned long long ra_t0_ = __builtin_amdgcn_s_memtime(); const bool ra_p_ = blockIdx.x == 0 && threadIdx.x == 0
+#define RA_PROF(k)                                                  \
+  do {                                                              \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+    if (ra_p_) g_ra_prof[k] += t_ - ra_t0_;                         \
+    ra_t0_ = t_;                                                    \
+  } while (0)
+#else
+#define RA_PROF_DECL
+#define RA_PROF(k)
+#define RA_COUNT(k, v)
+#endif
+
 constexpr int kWave = 64;
 constexpr int kRaAhead = 8; // interior-loop terms fetched ahead of the fold in k_inside / k_outside
 constexpr int kWavesPerBlock = 4;
@@ -85,6 +106,30 @@ __device__ __forceinline__ double dangle_energy(const RaLds &lds, const SeqView 
   return x;
 }
 
+// Which cells of a band table hold a value: one 128-bit mask per START position (bit = span), kept in LDS for
+// the last 128 starts.  The two big folds (Alpha_stemend over the enclosed stems, Beta_stem over the enclosing
+// pairs) walk their <= 496 (u1, u2) terms in the reference's order; only the terms whose table entry is not
+// -INF take part (about one in three for the cells that fold at all), and a lane finds them as the set bits of a
+// window of the row masks instead of testing every term.
+struct RowMasks {
+  uint32_t m[128][5]; // 128 bits + a zero word, so that a 32-bit window may start in the last word
+};
+__device__ __forceinline__ void rowmask_clear(RowMasks &r, int start) {
+#pragma unroll
+  for (int k = 0; k < 5; k++) r.m[start & 127][k] = 0;
+}
+__device__ __forceinline__ void rowmask_set(RowMasks &r, int start, int span) { r.m[start & 127][span >> 5] |= 1u << (span & 31); }
+// bits [lo, hi] of row `start` as a 32-bit word, bit 0 = span lo (0 <= lo <= 127, hi - lo <= 31; 0 if hi < lo)
+__device__ __forceinline__ uint32_t rowmask_window(const RowMasks &r, int start, int lo, int hi) {
+  if (hi < lo) return 0;
+  const uint32_t *row = r.m[start & 127];
+  const int k = lo >> 5;
+  const uint32_t a = row[k], b = row[k + 1];
+  const uint32_t w = __builtin_amdgcn_alignbit(b, a, (uint32_t)(lo & 31)); // (b:a) >> (lo & 31)
+  const int width = hi - lo + 1;
+  return width >= 32 ? w : (w & ((1u << width) - 1));
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -95,12 +140,17 @@ __global__ void k_fill(double *p, int64_t n, double value) {
 }
 
 // ------------------------------------------------------------------------------ inside
-__global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
+__global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
+  __shared__ RowMasks rowmasks[kWavesPerBlock];
   ra_load_lds(lds, c);
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (idx >= b.nseq) return;
+  RowMasks &rm = rowmasks[threadIdx.x >> 6]; // rows of Alpha_stem
+  RA_PROF_DECL;
+  const bool use_masks = b.W + 2 + kMaxLoop <= 128; // spans <= W + 1 fit a mask, live rows <= W + 2 + MAXLOOP fit the ring
+  for (int t = lane; t < 128; t += kWave) rowmask_clear(rm, t);
   using SL = RaSmallLayout;
   const SeqView v = make_view(b, idx);
   const int L = v.L, W = v.W, S = v.S;
@@ -117,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
     // lane mapping: d = dtop - lane, dtop = dmax, dmax-64, ...  (the last pass holds the
     // small spans, which are the cheap ones in every inside phase)
     const int dmax = imin(j, W + 1);
+    if (lane == 0) rowmask_clear(rm, j - 2); // the row that gets its first cell in column j + 1
 
     // phase 1: Alpha_stem (raccess.cpp:102-129) and Alpha_multi2 (:145-162): both need only
     // column j-1 and the cell itself.
@@ -142,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
         stem = flag ? temp : kNegInf;
       }
       EM(a_stem, i, j) = stem;
+      if (use_masks && stem != kNegInf) rowmask_set(rm, i, d);
       double temp = 0;
       bool flag = false;
       if (type != 0 && stem != kNegInf) {
@@ -159,6 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
       EM(a_multi2, i, j) = m2;
     }
     wave_sync();
+    RA_PROF(1);
 
     // phase 2: Alpha_multibif (:131-143) then Alpha_multi1 (:164-175)
     for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
@@ -185,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
       SM(a_multi1t, i, j) = m1;
     }
     wave_sync();
+    RA_PROF(2);
 
     // phase 3, two serial chains on two lanes: Alpha_multi (:177-191), i descending, and
     // Alpha_outer[j] (:230-241), p ascending.
@@ -216,10 +270,97 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
       ao[j] = temp;
     }
     wave_sync();
+    RA_PROF(3);
 
-    // phase 4: Alpha_stemend (:193-226).  Interior loops (u1 = p - i, u2 = j - q) are
-    // enumerated wave-uniformly in the reference's order: p ascending, q ascending.
-    if (j != L) {
+    // phase 4: Alpha_stemend (:193-226).  The enclosed stems (p = i + u1, q = j - u2) are folded in the
+    // reference's order - p ascending, q ascending - by the lane that owns the cell; a lane walks only the
+    // terms that exist (set bits of the rows of Alpha_stem, spans max(5, d - 30) .. d - u1), eight at a time:
+    // their band entries and sequence codes are fetched together, then folded one by one.
+    if (j != L && use_masks) {
+      const int bj = s[j]; // = s[j'-1] for the closing pair (i, j' = j+1)
+      for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+        const int d = dtop - lane;
+        const bool cell = d >= kTurn;
+        const int i = cell ? j - d : 0;
+        const int type = cell ? ra_bp(lds, s[i], s[j + 1]) : 0;
+        const int bi1 = cell ? s[i + 1] : 0;
+        double temp = type != 0 ? ra_hairpin_energy(lds, type, d, bi1, bj) : 0.0;
+        // this lane's terms: rows u1 = 0 .. m, p <= j - 5
+        const int m = type != 0 ? imin(kMaxLoop, d - (kTurn + 2)) : -1;
+        const int span_lo = imax(kTurn + 2, d - kMaxLoop);
+        int u1 = -1;
+        uint32_t wbits = 0; // the terms left in row u1: bit b = span span_lo + b
+        bool more = m >= 0;
+        while (__ballot(more) != 0) {
+          // (1) the next eight terms of this lane: integer work and the row masks in LDS only
+          int su1[kRaAhead], sspan[kRaAhead];
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) {
+            int span = -1;
+            if (more) {
+              while (wbits == 0 && u1 < m) { // next row with a term
+                u1++;
+                wbits = rowmask_window(rm, i + u1, span_lo, d - u1 - (u1 == 0 ? 1 : 0)); // (p, q) == (i, j) is excluded (:207)
+              }
+              if (wbits != 0) {
+                span = span_lo + __builtin_ctz(wbits);
+                wbits &= wbits - 1;
+              } else {
+                more = false;
+              }
+            }
+            su1[t] = span >= 0 ? u1 : -1;
+            sspan[t] = span;
+          }
+          RA_PROF(19);
+          // (2) their band entries and sequence codes, all fetched together (a lane without a term reads its own cell)
+          double sts[kRaAhead];
+          int su2[kRaAhead], sq[kRaAhead], sq1[kRaAhead], sp0[kRaAhead], sp1[kRaAhead];
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) {
+            const bool ok = su1[t] >= 0;
+            const int p = ok ? i + su1[t] : i, q = ok ? p + sspan[t] : j;
+            su2[t] = j - q;
+            sts[t] = EM(a_stem, p, q);
+            sq[t] = s[q];
+            sq1[t] = s[q + 1];
+            sp0[t] = s[p];
+            sp1[t] = s[p + 1];
+          }
+          RA_PROF(20);
+          // the terms' values first (their table look-ups are independent of each other), then the fold: its
+          // chain of dependent logsumexp is what a column costs, nothing else should sit on it
+          double xs[kRaAhead];
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) {
+            const int type2 = ra_rtype(ra_bp(lds, sp1[t], sq[t])); // (not 0 where the stem exists)
+            const double z = ra_loop_energy_bf(lds, c.big, type, type2, su1[t] < 0 ? 0 : su1[t], su2[t], bi1, bj, sp0[t], sq1[t]);
+            xs[t] = (su1[t] >= 0 && sts[t] != kNegInf && type2 != 0) ? sts[t] + z : kNegInf;
+          }
+          RA_PROF(21);
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) {
+            RA_COUNT(18, __popcll(__ballot(xs[t] != kNegInf)));
+            RA_COUNT(17, (xs[t] != kNegInf && (xs[t] < temp - 17.4 || temp < xs[t] - 17.4)) ? 1 : 0);
+            if (xs[t] != kNegInf) temp = ra_lse(lds, temp, xs[t]);
+          }
+          RA_COUNT(16, 1);
+          RA_PROF(22);
+        }
+        if (cell) {
+          double out = kNegInf;
+          if (type != 0) {
+            const int tt = ra_rtype(type);
+            out = ra_lse(lds, temp,
+                         EM(a_multi, i, j) + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + bi1] +
+                             lds.small[SL::kDangle5 + tt * 5 + bj]);
+          }
+          EM(a_stemend, i, j) = out;
+        }
+      }
+    }
+    if (j != L && !use_masks) {
+      // (spans beyond the row masks: every (u1, u2) term of the window is enumerated wave-uniformly)
       const int bj = s[j]; // = s[j'-1] for the closing pair (i, j' = j+1)
       for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
         const int d = dtop - lane;
@@ -276,16 +417,22 @@ __global__ __launch_bounds__(kBlock) void k_inside(RaBatch b, RaConst c) {
       }
     }
     wave_sync();
+    RA_PROF(4);
   }
 }
 
 // ----------------------------------------------------------------------------- outside
-__global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
+__global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
+  __shared__ RowMasks rowmasks[kWavesPerBlock];
   ra_load_lds(lds, c);
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (idx >= b.nseq) return;
+  RA_PROF_DECL;
+  RowMasks &rm = rowmasks[threadIdx.x >> 6]; // rows of Beta_stemend
+  const bool use_masks = b.W + 2 + kMaxLoop <= 128;
+  for (int t = lane; t < 128; t += kWave) rowmask_clear(rm, t);
   using SL = RaSmallLayout;
   const SeqView v = make_view(b, idx);
   const int L = v.L, W = v.W, S = v.S;
@@ -320,15 +467,21 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
     const int dmax = imin(q, W + 1);
 
     // phase A: Beta_stemend (:278-279), copy from column q+1
+    if (use_masks && lane == 0) rowmask_clear(rm, q - W); // the row whose first cell comes in column q - 1 (spans >= W never exist)
     if (q != L) {
       for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
         const int d = dbot + lane;
         if (d > dmax) continue;
         const int p = q - d;
-        if (p != 0) EM(b_stemend, p, q) = d >= W ? kNegInf : EM(b_stem, p - 1, q + 1);
+        if (p != 0) {
+          const double se = d >= W ? kNegInf : EM(b_stem, p - 1, q + 1);
+          EM(b_stemend, p, q) = se;
+          if (use_masks && se != kNegInf) rowmask_set(rm, p, d);
+        }
       }
     }
     wave_sync();
+    RA_PROF(8);
 
     // phase B, serial chains: Beta_multi (:281-308), p ascending, on lane 0;
     // Beta_outer[q-1] on lane 1.
@@ -362,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
       beta_outer_at(q - 1);
     }
     wave_sync();
+    RA_PROF(9);
 
     if (q != L) {
       // phase C: Beta_multi1 (:310-324) then Beta_multibif (:354-364)
@@ -390,6 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
         EM(b_multibif, p, q) = mb;
       }
       wave_sync();
+      RA_PROF(10);
 
       // phase D: Beta_multi2 (:326-352)
       for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
@@ -421,10 +576,12 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
         EM(b_multi2, p, q) = flag ? temp : kNegInf;
       }
       wave_sync();
+      RA_PROF(11);
     }
 
-    // phase E: Beta_stem (:367-409).  Enclosing pairs (i = p - u1, j+1 = q + u2 + 1) are
-    // enumerated wave-uniformly in the reference's order: i ascending, j ascending.
+    // phase E: Beta_stem (:367-409).  Enclosing pairs (i = p - u1, j+1 = q + u2 + 1) in the reference's
+    // order: i ascending, j ascending.  As in k_inside's phase 4, a lane walks only the terms whose
+    // Beta_stemend entry exists (set bits of a window of the row masks), eight at a time: fetch, evaluate, fold.
     for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
       const int d = dbot + lane;
       const bool cell = d <= dmax;
@@ -434,35 +591,90 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
       const int bp0 = cell ? s[p] : 0, bq1 = cell ? s[q + 1] : 0;
       double temp = 0;
       if (t2raw != 0) temp = ao[p] + bo[q] + dangle_energy(lds, v, t2raw, p, q);
-      // j - i = d + u1 + u2 <= W + 1; the pass bound uses dbot
-      const int m = imin(kMaxLoop, W + 1 - dbot);
-      const int u1top = imin(m, q - dbot - 1); // i >= 1 for the smallest span of the pass
-      for (int u1 = u1top; u1 >= 0; u1--) {
-        const int u2top = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - dbot - u1);
-        const bool row = t2raw != 0 && u1 <= p - 1;
-        const int i = p - u1;
-        const int bi0 = row ? s[i] : 0, bi1 = row ? s[i + 1] : 0;
-        for (int u2lo = 0; u2lo <= u2top; u2lo += kRaAhead) { // blocks of terms, see k_inside
-          double ses[kRaAhead];
-          int sj[kRaAhead], sj1[kRaAhead];
+      if (use_masks) {
+        // rows u1 = u1max .. 0 (i = p - u1 >= 1), spans d + u1 .. d + u1 + u2max with j <= L - 1 and j - i <= W + 1
+        int u1 = t2raw != 0 ? imin(imin(kMaxLoop, p - 1), W + 1 - d) + 1 : 0; // (one above the first row)
+        uint32_t wbits = 0;
+        int span0 = 0; // span of bit 0 of wbits
+        bool more = t2raw != 0 && u1 > 0;
+        while (__ballot(more) != 0) {
+          int su1[kRaAhead], sspan[kRaAhead];
 #pragma unroll
-          for (int b = 0; b < kRaAhead; b++) {
-            const int u2 = u2lo + b;
-            // (i,j) == (p,q) is excluded (:377)
-            const bool ok = row && u2 <= u2top && !(u1 == 0 && u2 == 0) && d + u1 + u2 <= W + 1;
-            const int j = q + u2;
-            ses[b] = ok ? EM(b_stemend, i, j) : kNegInf;
-            sj[b] = ok ? s[j] : 0;
-            sj1[b] = ok ? s[j + 1] : 0;
+          for (int t = 0; t < kRaAhead; t++) {
+            int span = -1;
+            if (more) {
+              while (wbits == 0 && u1 > 0) { // next row with a term
+                u1--;
+                const int u2max = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - d - u1);
+                span0 = d + u1 + (u1 == 0 ? 1 : 0); // (i, j) == (p, q) is excluded (:377)
+                wbits = rowmask_window(rm, p - u1, span0, d + u1 + u2max);
+              }
+              if (wbits != 0) {
+                span = span0 + __builtin_ctz(wbits);
+                wbits &= wbits - 1;
+              } else {
+                more = false;
+              }
+            }
+            su1[t] = span >= 0 ? u1 : -1;
+            sspan[t] = span;
+          }
+          double ses[kRaAhead];
+          int su2[kRaAhead], sj[kRaAhead], sj1[kRaAhead], si0[kRaAhead], si1[kRaAhead];
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) {
+            const bool ok = su1[t] >= 0;
+            const int i = ok ? p - su1[t] : p, j = ok ? i + sspan[t] : q; // (a lane without a term reads its own cell)
+            su2[t] = j - q;
+            ses[t] = EM(b_stemend, i, j);
+            sj[t] = s[j];
+            sj1[t] = s[j + 1];
+            si0[t] = s[i];
+            si1[t] = s[i + 1];
+          }
+          double xs[kRaAhead];
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) {
+            const int type = ra_bp(lds, si0[t], sj1[t]);
+            const double z = ra_loop_energy_bf(lds, c.big, type, type2, su1[t] < 0 ? 0 : su1[t], su2[t], si1[t], sj[t], bp0, bq1);
+            xs[t] = (su1[t] >= 0 && ses[t] != kNegInf && type != 0) ? ses[t] + z : kNegInf;
           }
 #pragma unroll
-          for (int b = 0; b < kRaAhead; b++) {
-            const double se = ses[b];
-            if (se != kNegInf) {
-              const int type = ra_bp(lds, bi0, sj1[b]);
-              if (type != 0) {
-                const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2lo + b, bi1, sj[b], bp0, bq1);
-                temp = ra_lse(lds, temp, se + z);
+          for (int t = 0; t < kRaAhead; t++)
+            if (xs[t] != kNegInf) temp = ra_lse(lds, temp, xs[t]);
+        }
+      } else {
+        // (spans beyond the row masks: every (u1, u2) term of the window is enumerated wave-uniformly)
+        // j - i = d + u1 + u2 <= W + 1; the pass bound uses dbot
+        const int m = imin(kMaxLoop, W + 1 - dbot);
+        const int u1top = imin(m, q - dbot - 1); // i >= 1 for the smallest span of the pass
+        for (int u1 = u1top; u1 >= 0; u1--) {
+          const int u2top = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - dbot - u1);
+          const bool row = t2raw != 0 && u1 <= p - 1;
+          const int i = p - u1;
+          const int bi0 = row ? s[i] : 0, bi1 = row ? s[i + 1] : 0;
+          for (int u2lo = 0; u2lo <= u2top; u2lo += kRaAhead) { // blocks of terms, see k_inside
+            double ses[kRaAhead];
+            int sj[kRaAhead], sj1[kRaAhead];
+#pragma unroll
+            for (int b = 0; b < kRaAhead; b++) {
+              const int u2 = u2lo + b;
+              // (i,j) == (p,q) is excluded (:377)
+              const bool ok = row && u2 <= u2top && !(u1 == 0 && u2 == 0) && d + u1 + u2 <= W + 1;
+              const int j = q + u2;
+              ses[b] = ok ? EM(b_stemend, i, j) : kNegInf;
+              sj[b] = ok ? s[j] : 0;
+              sj1[b] = ok ? s[j + 1] : 0;
+            }
+#pragma unroll
+            for (int b = 0; b < kRaAhead; b++) {
+              const double se = ses[b];
+              if (se != kNegInf) {
+                const int type = ra_bp(lds, bi0, sj1[b]);
+                if (type != 0) {
+                  const double z = ra_loop_energy(lds, c.big, type, type2, u1, u2lo + b, bi1, sj[b], bp0, bq1);
+                  temp = ra_lse(lds, temp, se + z);
+                }
               }
             }
           }
@@ -489,6 +701,7 @@ __global__ __launch_bounds__(kBlock) void k_outside(RaBatch b, RaConst c) {
       }
     }
     wave_sync();
+    RA_PROF(12);
   }
   // remaining Beta_outer positions (columns stop at q = 4)
   if (lane == 1)
@@ -815,6 +1028,18 @@ __global__ __launch_bounds__(kBlock) void k_access(RaBatch b, RaConst c) {
 }
 
 } // namespace
+
+#ifdef PRB_GAP_PROFILE
+extern "C" int prb_debug_ra_profile(unsigned long long *out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ra_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ra_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int64_t vec_elems,
                      hipStream_t stream) {
