@@ -112,6 +112,13 @@ int prb_suffix_array(const uint8_t *text, int32_t n, int32_t *sa);
 
 /* ---- database ---- */
 int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out);
+/* The same with at most max_resident_pages of the database's pages in HBM at a time (0 = all, what
+ * prb_db_open does unless PRB_DB_RESIDENT_PAGES says otherwise): prb_search_page uploads the page it is
+ * asked for if it is not resident (the least recently used page makes room) and, with two pages or
+ * more, uploads the next page on a copy stream of its own while this one is searched.  For databases
+ * beyond HBM; results do not depend on it.  prb_db_page_uploads: pages uploaded so far. */
+int prb_db_open_streaming(prb_ctx *ctx, const char *prefix, int32_t max_resident_pages, prb_db **out);
+int64_t prb_db_page_uploads(const prb_db *db);
 void prb_db_close(prb_db *db);
 int prb_db_info(const prb_db *db, int32_t *hash_size, int32_t *repeat_flag, int32_t *maximal_span,
                 int32_t *min_accessible_length, int32_t *npages);

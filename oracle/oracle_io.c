@@ -135,7 +135,7 @@ orc_db *orc_db_open(const char *prefix) {
     int32_t nchars;
     if (rd_i32(seq, &nchars)) return NULL;
     pg->nchars = nchars;
-    pg->seqs = malloc(nchars ? nchars : 1);
+    pg->seqs = calloc((size_t)nchars + 64, 1); /* zero padding behind the text: see orc_extend_gapped */
     if (fread(pg->seqs, 1, nchars, seq) != (size_t)nchars) return NULL;
     /* seq_length_rep: count of unmasked codes per sequence, db_reader.cpp:122-131 */
     pg->seq_length_rep = calloc(nseq + 2, sizeof(int32_t));

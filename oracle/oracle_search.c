@@ -610,6 +610,13 @@ void orc_extend_gapped(const orc_db *db, int page, const orc_ris_opts *o, const 
                        const float *qacc, const float *qcond, orc_hits *hits) {
   const orc_page *pg = &db->pages[page];
   const int delta = db->min_accessible_length;
+  /* CheckHelixLength looks up to min_helix - 1 positions past a cell (GetBPType -> GetChar, gapped_extension.cpp:
+   * 321-338, 401-407) without an upper bound: next to the query's end the reference reads one or two bytes behind
+   * its vector (undefined; whatever the heap holds).  Defined here - and in the HIP path - as "no base": the query is
+   * copied into a zero-padded buffer.  (The page text is padded the same way where it is loaded, oracle_io.c.) */
+  uint8_t *qpad = calloc((size_t)qn + 64, 1);
+  memcpy(qpad, qenc, (size_t)qn);
+  qenc = qpad;
   /* GappedExtension::Run, gapped_extension.cpp:33-69 */
   for (size_t x = 0; x < hits->n; x++) {
     orc_hit *h = &hits->h[x];
@@ -629,6 +636,7 @@ void orc_extend_gapped(const orc_db *db, int page, const orc_ris_opts *o, const 
   for (size_t x = 1; x < hits->n; x++) qsort(hits->h[x].bp, hits->h[x].nbp, 2 * sizeof(int32_t), bp_cmp);
   sort_hits(hits);
   check_redundancy(hits, o->final_thr);
+  free(qpad);
 }
 
 /* ------------------------------------------------------------------- whole `ris` */

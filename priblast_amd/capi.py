@@ -58,6 +58,8 @@ SYMBOLS = {
     "prb_encode_query": (ctypes.c_int, [ctypes.c_char_p, c_i32, c_i32, ctypes.c_void_p]),
     "prb_suffix_array": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p]),
     "prb_db_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, P(ctypes.c_void_p)]),
+    "prb_db_open_streaming": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_i32, P(ctypes.c_void_p)]),
+    "prb_db_page_uploads": (c_i64, [ctypes.c_void_p]),
     "prb_db_close": (None, [ctypes.c_void_p]),
     "prb_db_info": (ctypes.c_int, [ctypes.c_void_p, P(c_i32), P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
     "prb_db_page_info": (ctypes.c_int, [ctypes.c_void_p, c_i32, P(c_i32), P(c_i64)]),
@@ -211,9 +213,12 @@ class Context:
 class Db:
     """Database pages resident in HBM (prb_db_open)."""
 
-    def __init__(self, ctx, prefix):
+    def __init__(self, ctx, prefix, max_resident_pages=None):
         h = ctypes.c_void_p()
-        _check(lib().prb_db_open(ctx.h, prefix.encode(), ctypes.byref(h)))
+        if max_resident_pages is None:
+            _check(lib().prb_db_open(ctx.h, prefix.encode(), ctypes.byref(h)))
+        else:
+            _check(lib().prb_db_open_streaming(ctx.h, prefix.encode(), max_resident_pages, ctypes.byref(h)))
         self.h, self.ctx = h, ctx
         v = [c_i32() for _ in range(5)]
         _check(lib().prb_db_info(self.h, *[ctypes.byref(x) for x in v]))
@@ -223,6 +228,10 @@ class Db:
         if self.h:
             lib().prb_db_close(self.h)
             self.h = None
+
+    @property
+    def page_uploads(self):
+        return lib().prb_db_page_uploads(self.h)
 
     def page_info(self, page):
         n, c = c_i32(), c_i64()

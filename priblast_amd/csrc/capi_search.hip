@@ -179,7 +179,19 @@ struct prb_db {
   prb_ctx *ctx = nullptr;
   DbHeader hdr;
   std::vector<DbPage> pages;
+  // Device residency (DbReader::LoadDatabases loads every page eagerly, db_reader.cpp:29-59; here a database
+  // larger than HBM - or than the share of it one wants to give it - is streamed): `mem` are slots, at most
+  // max_resident of them; a page that is searched is uploaded into a slot if it is not there (the least recently
+  // used page makes room), and with two slots or more the NEXT page's upload runs on a copy stream of its own
+  // while this one is searched (the host copies are page-locked for that).
   std::vector<PageMem> mem;
+  std::vector<int> slot_of_page, page_in_slot;
+  std::vector<uint64_t> slot_used; // "time" of the last search that used the slot
+  std::vector<hipEvent_t> slot_ready;
+  uint64_t clock = 0;
+  hipStream_t copy_stream = nullptr;
+  bool pinned = false;
+  int64_t uploads = 0; // pages uploaded so far (tests)
   std::vector<SeqTable> tabs; // per page: what the result lines print about its sequences
 };
 
@@ -301,11 +313,11 @@ void prb_search_const_free(prb_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------------ database
-static int upload_page(prb_ctx *ctx, const DbPage &pg, PageMem &m) {
+static int upload_page(const DbPage &pg, PageMem &m, hipStream_t stream) {
   int rc;
   auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
     if ((rc = b.ensure(std::max<size_t>(bytes, 16)))) return rc;
-    if (bytes) PRB_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (bytes) PRB_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, stream));
     return PRB_OK;
   };
   if ((rc = up(m.seqs, pg.seqs.data(), pg.seqs.size()))) return rc;
@@ -324,13 +336,41 @@ static int upload_page(prb_ctx *ctx, const DbPage &pg, PageMem &m) {
   m.view.cond = m.cond.as<float>();
   m.view.nchars = (int32_t)pg.seqs.size();
   m.view.nseq = pg.nseq;
-  PRB_HIP(launch_sa_seq(m.view, m.sa_seq.as<int32_t>(), ctx->stream));
-  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  PRB_HIP(launch_sa_seq(m.view, m.sa_seq.as<int32_t>(), stream));
   return PRB_OK;
 }
 
-int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
-  if (!ctx || !prefix || !out) return PRB_ERR_ARG;
+// Page `page` on the device: its slot, uploaded now if need be (on `stream`; the slot's event is recorded behind
+// the upload).  `keep` = a page whose slot must not be taken (the one being searched), or -1.
+static int page_slot(prb_ctx *user, prb_db *db, int page, int keep, hipStream_t stream, int *slot_out) {
+  int slot = db->slot_of_page[page];
+  if (slot < 0) {
+    // a free slot, else the least recently used one
+    for (size_t k = 0; k < db->page_in_slot.size() && slot < 0; k++)
+      if (db->page_in_slot[k] < 0) slot = (int)k;
+    if (slot < 0) {
+      for (size_t k = 0; k < db->page_in_slot.size(); k++)
+        if (db->page_in_slot[k] != keep && (slot < 0 || db->slot_used[k] < db->slot_used[(size_t)slot])) slot = (int)k;
+      if (slot < 0) return PRB_ERR_STATE;
+      // what still reads the slot's old page (a search on the context's stream, an earlier upload) must be over
+      PRB_HIP(hipStreamSynchronize(user->stream));
+      PRB_HIP(hipEventSynchronize(db->slot_ready[(size_t)slot]));
+      db->slot_of_page[(size_t)db->page_in_slot[(size_t)slot]] = -1;
+    }
+    int rc = upload_page(db->pages[(size_t)page], db->mem[(size_t)slot], stream);
+    if (rc) return rc;
+    PRB_HIP(hipEventRecord(db->slot_ready[(size_t)slot], stream));
+    db->page_in_slot[(size_t)slot] = page;
+    db->slot_of_page[(size_t)page] = slot;
+    db->uploads++;
+  }
+  db->slot_used[(size_t)slot] = ++db->clock;
+  *slot_out = slot;
+  return PRB_OK;
+}
+
+int prb_db_open_streaming(prb_ctx *ctx, const char *prefix, int32_t max_resident_pages, prb_db **out) {
+  if (!ctx || !prefix || !out || max_resident_pages < 0) return PRB_ERR_ARG;
   *out = nullptr;
   auto *db = new prb_db();
   db->ctx = ctx;
@@ -340,17 +380,48 @@ int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
     delete db;
     return PRB_ERR_IO;
   }
-  PRB_HIP(hipSetDevice(ctx->device));
-  db->mem.resize(db->pages.size());
-  for (size_t i = 0; i < db->pages.size(); i++) {
-    int rc = upload_page(ctx, db->pages[i], db->mem[i]);
-    if (rc) {
-      prb_db_close(db);
-      return rc;
-    }
+  if (hipSetDevice(ctx->device) != hipSuccess) {
+    delete db;
+    return hip_fail(hipErrorInvalidDevice, "hipSetDevice");
   }
-  db->tabs.resize(db->pages.size());
-  for (size_t i = 0; i < db->pages.size(); i++) {
+  const size_t np = db->pages.size();
+  const size_t nslots = max_resident_pages == 0 ? np : std::min<size_t>(np, (size_t)max_resident_pages);
+  db->mem.resize(nslots);
+  db->page_in_slot.assign(nslots, -1);
+  db->slot_used.assign(nslots, 0);
+  db->slot_of_page.assign(np, -1);
+  db->slot_ready.assign(nslots, nullptr);
+  int rc = PRB_OK;
+  for (size_t k = 0; k < nslots && rc == PRB_OK; k++)
+    if (hipEventCreateWithFlags(&db->slot_ready[k], hipEventDisableTiming) != hipSuccess) rc = PRB_ERR_HIP;
+  if (rc == PRB_OK && nslots < np) {
+    // streaming: uploads of the next page run beside the search on a stream of their own, from page-locked memory
+    if (hipStreamCreateWithFlags(&db->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = PRB_ERR_HIP;
+    for (DbPage &pg : db->pages) {
+      if (rc != PRB_OK) break;
+      auto pin = [&](void *p, size_t bytes) {
+        if (bytes && hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) rc = PRB_ERR_HIP;
+      };
+      pin(pg.seqs.data(), pg.seqs.size());
+      pin(pg.sa.data(), pg.sa.size() * 4);
+      pin(pg.acc.data(), pg.acc.size() * 4);
+      pin(pg.cond.data(), pg.cond.size() * 4);
+    }
+    db->pinned = rc == PRB_OK;
+    if (rc != PRB_OK) set_error("prb_db_open: cannot set up page streaming (stream / page-locked host memory)");
+  }
+  // the first pages are resident from the start
+  for (size_t i = 0; i < nslots && rc == PRB_OK; i++) {
+    int slot = -1;
+    rc = page_slot(ctx, db, (int)i, -1, ctx->stream, &slot);
+  }
+  if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;
+  if (rc != PRB_OK) {
+    prb_db_close(db);
+    return rc;
+  }
+  db->tabs.resize(np);
+  for (size_t i = 0; i < np; i++) {
     const DbPage &pg = db->pages[i];
     db->tabs[i] = SeqTable{pg.names, pg.seq_length, pg.seq_length_rep, pg.start_pos};
   }
@@ -358,8 +429,30 @@ int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
   return PRB_OK;
 }
 
+int prb_db_open(prb_ctx *ctx, const char *prefix, prb_db **out) {
+  const char *e = getenv("PRB_DB_RESIDENT_PAGES"); // 0 / unset: every page resident
+  return prb_db_open_streaming(ctx, prefix, e ? std::max(0, atoi(e)) : 0, out);
+}
+
+int64_t prb_db_page_uploads(const prb_db *db) { return db ? db->uploads : -1; }
+
 void prb_db_close(prb_db *db) {
   if (!db) return;
+  (void)hipSetDevice(db->ctx->device);
+  (void)hipStreamSynchronize(db->ctx->stream);
+  if (db->copy_stream) {
+    (void)hipStreamSynchronize(db->copy_stream);
+    (void)hipStreamDestroy(db->copy_stream);
+  }
+  for (hipEvent_t e : db->slot_ready)
+    if (e) (void)hipEventDestroy(e);
+  if (db->pinned)
+    for (DbPage &pg : db->pages) {
+      if (!pg.seqs.empty()) (void)hipHostUnregister(pg.seqs.data());
+      if (!pg.sa.empty()) (void)hipHostUnregister(pg.sa.data());
+      if (!pg.acc.empty()) (void)hipHostUnregister(pg.acc.data());
+      if (!pg.cond.empty()) (void)hipHostUnregister(pg.cond.data());
+    }
   for (auto &m : db->mem)
     for (DevBuf *b : {&m.seqs, &m.sa, &m.sa_seq, &m.start_pos, &m.seq_length, &m.acc, &m.cond}) b->release();
   delete db;
@@ -769,7 +862,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   SearchWs &w = ws_of(ctx);
   const SearchConst &sc = static_cast<SearchConstMem *>(ctx->search_const)->view;
   const DbPage &pg = db->pages[page];
-  const PageDev &pd = db->mem[page].view;
+  const PageDev &pd = db->mem[(size_t)db->slot_of_page[(size_t)page]].view;
   const int delta = db->hdr.min_accessible_length;
   ExtOpts eo{delta, opts.drop_out_wo_gap, opts.drop_out_w_gap, opts.min_helix_length};
   int rc;
@@ -1181,6 +1274,19 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   }
   PRB_HIP(hipSetDevice(ctx->device));
   const DbPage &pg = db->pages[page];
+  {
+    // the page on the device (uploaded now unless it is resident or was prefetched), then - while it is searched -
+    // the next page on the copy stream
+    int slot = -1, rcp;
+    if ((rcp = page_slot(ctx, db, page, -1, ctx->stream, &slot))) return rcp;
+    PRB_HIP(hipStreamWaitEvent(ctx->stream, db->slot_ready[(size_t)slot], 0));
+    const int next = page + 1 < (int32_t)db->pages.size() ? page + 1 : 0;
+    if (db->copy_stream && db->mem.size() >= 2 && next != page && db->slot_of_page[(size_t)next] < 0) {
+      int ns = -1;
+      if ((rcp = page_slot(ctx, db, next, page, db->copy_stream, &ns))) return rcp;
+      db->slot_used[(size_t)slot] = ++db->clock; // (the page being searched is the most recently used one)
+    }
+  }
   // Seed search proper: DFS over the two suffix arrays, per query, on host threads.  It runs
   // in the background while the GPU already works on the first sub-batches: the consumer below
   // only waits for the queries it is about to submit.

@@ -150,3 +150,10 @@ def test_native_gather_matches_the_host_statement(golden_dir):
         qb.close()
         db.close()
         comm.close()
+
+
+def test_cli_with_a_streamed_database(golden_dir, tmp_path):
+    """PRB_DB_RESIDENT_PAGES=1 / 2 on the 3-page database, several batches: the file of the fully resident run"""
+    plain = _run_ris(tmp_path, golden_dir, "plain.txt", {"PRB_BATCH": "3"})
+    for cap in ("1", "2"):
+        assert _run_ris(tmp_path, golden_dir, f"s{cap}.txt", {"PRB_BATCH": "3", "PRB_DB_RESIDENT_PAGES": cap}) == plain

@@ -217,3 +217,35 @@ def test_query_longer_than_the_lds_staging(ctx, oracle, golden_dir):
         qb.close()
         db.close()
         odb.close()
+
+
+@pytest.mark.parametrize("tag", ["mix", "quirk"])
+def test_streamed_database_gives_the_same_hits(ctx, golden_dir, tag):
+    """a database opened with a residency cap of one page (every search uploads its page) and of
+    two pages (the next page's upload overlaps the search) gives the hits of the fully resident database, pass
+    after pass over the pages."""
+    from priblast_amd import capi
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
+    prefix = os.path.join(golden_dir, f"{tag}db")
+
+    def run(cap):
+        db = capi.Db(ctx, prefix, cap)
+        qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+        qb.accessibility(db.W, db.delta)
+        out = []
+        for _ in range(2):  # two passes: the second one finds other pages resident than the first
+            for page in range(db.npages):
+                hits, bp, counts = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
+                out.append((hits.copy(), bp.copy(), counts))
+        ups, np_ = db.page_uploads, db.npages
+        qb.close()
+        db.close()
+        return out, ups, np_
+    full, ups_full, npages = run(None)
+    assert npages >= 3 and ups_full == npages
+    for cap in (1, 2):
+        got, ups, _ = run(cap)
+        assert ups > npages, (cap, ups)  # pages really came and went
+        assert len(got) == len(full)
+        for (h1, b1, c1), (h2, b2, c2) in zip(got, full):
+            assert c1 == c2 and np.array_equal(h1, h2) and np.array_equal(b1, b2)
