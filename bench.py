@@ -65,6 +65,7 @@ def parse():
                     help="queries in the CPU baseline sample (-1: one per thread; 0: skip)")
     ap.add_argument("--cpu-db-fraction", type=int, default=int(os.environ.get("BENCH_CPU_DB_FRACTION", 0)),
                     help="the CPU baseline runs against the first 1/F of the database (0: sized so that a query costs ~20 core-s)")
+    ap.add_argument("--force-comm", action="store_true", help="run the N > 1 code path (RCCL communicator, final hit gather) with one rank")
     ap.add_argument("--no-overlap", action="store_true", help="accessibilities of a batch inside its own step (no second context)")
     ap.add_argument("--workdir", default=os.environ.get("BENCH_WORKDIR", os.path.join(tempfile.gettempdir(), "priblast_bench")))
     return ap.parse_args()
@@ -215,11 +216,16 @@ def main():
     # host threads for the per-query host work (suffix arrays, seed DFS, line formatting): share the box among the ranks
     os.environ.setdefault("PRB_HOST_THREADS", str(max(8, min(32, host_cores() // max(world, 1)))))
     torch.cuda.set_device(local)
+    multi = world > 1 or a.force_comm
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif a.force_comm:
+        os.makedirs(a.workdir, exist_ok=True)
+        store = os.path.join(a.workdir, f"rdv_{os.getpid()}")
+        dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -252,7 +258,7 @@ def main():
     shape = {(5000, 1000): "BASELINE configs[1] shape", (50000, 2000): "BASELINE configs[2]: the full 50,000 x 2 kb database, a contiguous sample of its 50,000 queries",
              (32, 200): "BASELINE configs[0] shape"}.get((a.db_seqs, a.length), "not a BASELINE config")
     devnull = os.open(os.devnull, os.O_WRONLY)
-    comm = pdist.NativeComm(ctx, rank, world) if world > 1 else None
+    comm = pdist.NativeComm(ctx, rank, world) if multi else None
 
     wall = collections.defaultdict(float)
     sink = {"lines": 0, "bytes": 0}
@@ -319,7 +325,7 @@ def main():
         wall["search (DFS + GPU stages + download)"] += time.perf_counter() - t2
         names = qnames[lo:hi]
         pages = [(hs.hits, hs.bp) for hs in sets]
-        if world > 1:  # final hit gather over RCCL: the packed records of every rank's batch, device to device, to rank 0
+        if multi:  # final hit gather over RCCL: the packed records of every rank's batch, device to device, to rank 0
             t3 = time.perf_counter()
             got = comm.gather_batch(sets, qlen)
             if rank == 0:
@@ -358,7 +364,7 @@ def main():
     drain()
     barrier()
     dt = time.perf_counter() - t
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -395,7 +401,7 @@ def main():
                        "hits_per_step": {"seed": allc[0] // a.steps, "ungapped": allc[1] // a.steps, "final": allc[2] // a.steps},
                        "result_lines_per_step": sink["lines"] // a.steps, "result_text_bytes_per_step": sink["bytes"] // a.steps,
                        "pipeline": "none" if ctx2 is None else "accessibilities of batch k+1 and lines of batch k-1 overlap the search of batch k",
-                       "parallelism": f"queries sharded over {world} GPU(s)" + (", final hits gathered on rank 0 over RCCL" if world > 1 else "")},
+                       "parallelism": f"queries sharded over {world} GPU(s)" + (", final hits gathered on rank 0 over RCCL" if multi else "")},
             "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
             "lane_kernel_hits_per_step": ctx.stage_ms("gapped_lane_hits")[1] // a.steps,
@@ -418,7 +424,7 @@ def main():
         ctx2.close()
     ctx.close()
     os.close(devnull)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -97,27 +97,16 @@ void prb_ris_opts_default(prb_ris_opts *o) {
 int prb_search_const_upload(prb_ctx *ctx); // capi_search.hip
 void prb_search_const_free(prb_ctx *ctx);
 
-int prb_ctx_create(int device, const char *param_file, prb_ctx **out) {
-  if (!out) return PRB_ERR_ARG;
-  *out = nullptr;
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev == 0) {
-    set_error("no HIP device available (this library has no CPU path)");
-    return PRB_ERR_HIP;
-  }
-  if (device < 0 || device >= ndev) {
-    set_error("device index out of range");
-    return PRB_ERR_ARG;
-  }
+} // extern "C" (reopened below)
+
+// everything of prb_ctx_create that can fail half-way: the caller destroys the context then
+static int ctx_init(prb_ctx *ctx, int device, const char *param_file) {
   PRB_HIP(hipSetDevice(device));
-  prb_ctx *ctx = new prb_ctx();
   ctx->device = device;
   std::string pf = param_file ? param_file : default_param_file();
   std::string err = load_energy_params(pf, ctx->params);
   if (!err.empty()) {
     set_error(err);
-    delete ctx;
     return PRB_ERR_IO;
   }
   build_raccess_tables(ctx->params, ctx->ra_tables);
@@ -154,9 +143,43 @@ int prb_ctx_create(int device, const char *param_file, prb_ctx **out) {
   // with fewer sequences than that is bound by the latency of one sequence, not by throughput
   double gb = env ? atof(env) : 48.0;
   ctx->ra_budget_bytes = (size_t)std::min(gb * (double)(1ull << 30), 0.5 * (double)free_b);
+  return PRB_OK;
+}
+
+extern "C" {
+
+int prb_ctx_create(int device, const char *param_file, prb_ctx **out) {
+  if (!out) return PRB_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("no HIP device available (this library has no CPU path)");
+    return PRB_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("device index out of range");
+    return PRB_ERR_ARG;
+  }
+  prb_ctx *ctx = nullptr;
+  int rc;
+  try {
+    ctx = new prb_ctx();
+    rc = ctx_init(ctx, device, param_file);
+  } catch (const std::exception &ex) { // (no exception leaves the C ABI)
+    set_error(std::string("prb_ctx_create: ") + ex.what());
+    rc = PRB_ERR_NOMEM;
+  }
+  if (rc != PRB_OK) {
+    const std::string keep = prb_last_error(); // (destroying must not lose the reason)
+    if (ctx) prb_ctx_destroy(ctx);
+    set_error(keep);
+    return rc;
+  }
   *out = ctx;
   return PRB_OK;
 }
+
 
 void prb_ctx_destroy(prb_ctx *ctx) {
   if (!ctx) return;

@@ -374,7 +374,12 @@ int prb_db_open_streaming(prb_ctx *ctx, const char *prefix, int32_t max_resident
   *out = nullptr;
   auto *db = new prb_db();
   db->ctx = ctx;
-  std::string err = read_db(prefix, db->hdr, db->pages);
+  std::string err;
+  try {
+    err = read_db(prefix, db->hdr, db->pages);
+  } catch (const std::exception &e) { // (no exception leaves the C ABI)
+    err = std::string("Error: cannot load the database: ") + e.what();
+  }
   if (!err.empty()) {
     set_error(err);
     delete db;
@@ -596,7 +601,10 @@ int prb_qbatch_create(prb_ctx *ctx, int32_t nq, const char *seqs, const int64_t 
     for (int32_t k = 0; k <= L; k++) c += qb->enc[o + k] >= 2 && qb->enc[o + k] <= 5; // rna_interaction_search.cpp:179-183
     qb->len_unmasked[q] = c;
   }
-  PRB_HIP(hipSetDevice(ctx->device));
+  if (hipError_t e = hipSetDevice(ctx->device); e != hipSuccess) {
+    delete qb;
+    return hip_fail(e, "hipSetDevice");
+  }
   int rc = 0;
   const size_t n = (size_t)t;
   if ((rc = qb->d_enc.ensure(n)) || (rc = qb->d_sa.ensure(n * 4)) || (rc = qb->d_acc.ensure(n * 4)) ||
@@ -605,13 +613,19 @@ int prb_qbatch_create(prb_ctx *ctx, int32_t nq, const char *seqs, const int64_t 
     prb_qbatch_destroy(qb);
     return rc;
   }
-  PRB_HIP(hipMemcpyAsync(qb->d_enc.p, qb->enc.data(), n, hipMemcpyHostToDevice, ctx->stream));
-  PRB_HIP(hipMemcpyAsync(qb->d_sa.p, qb->sa.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-  PRB_HIP(hipMemcpyAsync(qb->d_off.p, qb->off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  PRB_HIP(hipMemcpyAsync(qb->d_len.p, qb->len.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
-  PRB_HIP(hipMemsetAsync(qb->d_acc.p, 0, n * 4, ctx->stream));
-  PRB_HIP(hipMemsetAsync(qb->d_cond.p, 0, n * 4, ctx->stream));
-  PRB_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    hipError_t e = hipMemcpyAsync(qb->d_enc.p, qb->enc.data(), n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(qb->d_sa.p, qb->sa.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(qb->d_off.p, qb->off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(qb->d_len.p, qb->len.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(qb->d_acc.p, 0, n * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(qb->d_cond.p, 0, n * 4, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      prb_qbatch_destroy(qb);
+      return hip_fail(e, "prb_qbatch_create: upload");
+    }
+  }
   qb->view.enc = qb->d_enc.as<uint8_t>();
   qb->view.sa = qb->d_sa.as<int32_t>();
   qb->view.acc = qb->d_acc.as<float>();
@@ -1267,9 +1281,9 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     return PRB_ERR_STATE;
   }
   if (opts->drop_out_w_gap < 0 || opts->drop_out_w_gap > 30 || opts->drop_out_wo_gap < 1 || opts->drop_out_wo_gap > 15 ||
-      opts->min_helix_length < 1 || opts->min_helix_length > 16 || opts->max_seed_length < 1) {
+      opts->min_helix_length < 1 || opts->min_helix_length > 16 || opts->max_seed_length < 1 || opts->max_seed_length > 63) {
     set_error("unsupported option: need 0 <= -x <= 30, 1 <= -y <= 15 (beyond that the reference reads outside its "
-              "31-entry loop tables), 1 <= -m <= 16, -l >= 1");
+              "31-entry loop tables), 1 <= -m <= 16, 1 <= -l <= 63 (the seed search keeps a path of 64 characters)");
     return PRB_ERR_ARG;
   }
   PRB_HIP(hipSetDevice(ctx->device));

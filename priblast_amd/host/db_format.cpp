@@ -38,6 +38,7 @@ std::string read_db(const std::string &prefix, DbHeader &hdr, std::vector<DbPage
   for (;;) {
     int32_t nseq;
     if (!seq.rd(&nseq, 4)) break; // EOF on .seq ends the database (db_reader.cpp:73-82)
+    if (nseq < 0 || nseq > (1 << 28)) return "Error: corrupt " + prefix + ".seq (sequence count)";
     pages.emplace_back();
     DbPage &pg = pages.back();
     pg.nseq = nseq;
@@ -46,11 +47,15 @@ std::string read_db(const std::string &prefix, DbHeader &hdr, std::vector<DbPage
     pg.start_pos.resize(nseq);
     int64_t t = 0;
     for (int i = 0; i < nseq; i++) {
+      if (pg.seq_length[i] < 0) return "Error: corrupt " + prefix + ".seq (negative sequence length)";
       pg.start_pos[i] = (int32_t)t;
       t += pg.seq_length[i] + 1;
     }
     int32_t nchars;
     if (!seq.rd(&nchars, 4)) return "Error: truncated " + prefix + ".seq";
+    // the text is the sequences, each followed by a 0 (db_construction.cpp:371-392): the kernels index it, the
+    // suffix array and the k-mer table with these numbers, so they are checked once here
+    if (nchars < 0 || (int64_t)nchars != t) return "Error: corrupt " + prefix + ".seq (text length does not match the sequence lengths)";
     pg.seqs.resize(nchars);
     if (!seq.rd(pg.seqs.data(), (size_t)nchars)) return "Error: truncated " + prefix + ".seq";
     {
@@ -73,11 +78,13 @@ std::string read_db(const std::string &prefix, DbHeader &hdr, std::vector<DbPage
       int32_t n;
       if (!acc.rd(&n, 4)) return "Error: truncated " + prefix + ".acc";
       if (n < 0) n = 0;
+      if (n > L + 1) return "Error: corrupt " + prefix + ".acc (more values than positions)";
       tmp.resize(n);
       if (!acc.rd(tmp.data(), 4 * (size_t)n)) return "Error: truncated " + prefix + ".acc";
       std::memcpy(pg.acc.data() + base, tmp.data(), 4 * (size_t)std::min<int64_t>(n, L));
       if (!acc.rd(&n, 4)) return "Error: truncated " + prefix + ".acc";
       if (n < 0) n = 0;
+      if (n > L + 1) return "Error: corrupt " + prefix + ".acc (more values than positions)";
       tmp.resize(n);
       if (!acc.rd(tmp.data(), 4 * (size_t)n)) return "Error: truncated " + prefix + ".acc";
       std::memcpy(pg.cond.data() + base, tmp.data(), 4 * (size_t)std::min<int64_t>(n, L));
@@ -86,8 +93,11 @@ std::string read_db(const std::string &prefix, DbHeader &hdr, std::vector<DbPage
     for (int i = 0; i < nseq; i++) std::getline(nam, pg.names[i]);
     int32_t nsa;
     if (!ind.rd(&nsa, 4)) return "Error: truncated " + prefix + ".ind";
+    if (nsa != nchars) return "Error: corrupt " + prefix + ".ind (suffix array length does not match the text)";
     pg.sa.resize(nsa);
     if (!ind.rd(pg.sa.data(), 4 * (size_t)nsa)) return "Error: truncated " + prefix + ".ind";
+    for (int32_t v : pg.sa)
+      if (v < 0 || v >= nchars) return "Error: corrupt " + prefix + ".ind (suffix array entry out of range)";
     pg.start_hash.resize(hdr.hash_size);
     pg.end_hash.resize(hdr.hash_size);
     for (int pass = 0; pass < 2; pass++) {
@@ -96,6 +106,9 @@ std::string read_db(const std::string &prefix, DbHeader &hdr, std::vector<DbPage
         auto &h = pass == 0 ? pg.start_hash[i] : pg.end_hash[i];
         h.resize(n);
         if (!ind.rd(h.data(), 4 * n)) return "Error: truncated " + prefix + ".ind";
+        // an interval of the suffix array, or the empty one stored as (1, 0)
+        for (int32_t v : h)
+          if (v < 0 || v > nsa) return "Error: corrupt " + prefix + ".ind (k-mer interval out of range)";
       }
     }
   }

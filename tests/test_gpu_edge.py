@@ -249,3 +249,49 @@ def test_streamed_database_gives_the_same_hits(ctx, golden_dir, tag):
         assert len(got) == len(full)
         for (h1, b1, c1), (h2, b2, c2) in zip(got, full):
             assert c1 == c2 and np.array_equal(h1, h2) and np.array_equal(b1, b2)
+
+
+def test_corrupt_database_and_seed_length_limit_fail_loudly(ctx, golden_dir, tmp_path):
+    """Counts and indices of the database files are checked when they are loaded (the kernels index the text, the
+    suffix array and the k-mer table with them): an out-of-range suffix array entry, a text length that does not match
+    the sequence lengths and a truncated file are errors with a message, not device faults or exceptions; -l beyond the
+    seed search's 63-character path is refused instead of silently clamped."""
+    import shutil
+    from priblast_amd import capi
+    src = os.path.join(golden_dir, "c1db")
+
+    def variant(name, edit):
+        dst = str(tmp_path / name)
+        for ext in ("bas", "seq", "acc", "nam", "ind"):
+            shutil.copy(f"{src}.{ext}", f"{dst}.{ext}")
+        edit(dst)
+        return dst
+
+    def bad_sa(dst):
+        a = np.fromfile(dst + ".ind", dtype="<i4")
+        a[5] = a[0] + 7  # beyond the text
+        a.tofile(dst + ".ind")
+
+    def bad_len(dst):
+        a = np.fromfile(dst + ".seq", dtype=np.uint8)
+        a[4:8] = np.array([201], "<i4").view(np.uint8)  # first sequence one longer than the text has room for
+        a.tofile(dst + ".seq")
+
+    def truncated(dst):
+        with open(dst + ".acc", "r+b") as f:
+            f.truncate(1000)
+    for name, edit in (("sa", bad_sa), ("len", bad_len), ("trunc", truncated)):
+        with pytest.raises(capi.PrbError) as e:
+            capi.Db(ctx, variant(name, edit))
+        assert "corrupt" in str(e.value) or "truncated" in str(e.value), str(e.value)
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "c1_q.fa"))
+    db = capi.Db(ctx, src)
+    qb = capi.QBatch(ctx, seqs[:2], db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        with pytest.raises(capi.PrbError):
+            capi.search_page(ctx, qb, db, 0, capi.default_opts(max_seed_length=64))
+        capi.search_page(ctx, qb, db, 0, capi.default_opts(max_seed_length=63))
+    finally:
+        qb.close()
+        db.close()
