@@ -749,7 +749,7 @@ __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v,
           valid = type2 != 0 && as != kNegInf;
           if (valid) {
             type2 = ra_rtype(type2);
-            const double e = bs + ra_loop_energy(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
+            const double e = bs + ra_loop_energy_bf(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
             val = kLogSum ? e : ra_expd(lds, e);
           }
         }
@@ -860,40 +860,47 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
       const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
       const int bi1 = s[i + 1], bj1 = s[j - 1];
       const int kr1 = j - delta;
-      for (int u1 = 0; u1 <= m; u1++) {
+      // two rows (u1, u1 + 1) per pass, 32 lanes each: the flags are ORs, so the order of the tuples does not matter;
+      // straight-line evaluation (branch-free loop energy: the lanes' loops are of different classes)
+      for (int u1a = 0; u1a <= m; u1a += 2) {
+        const int half = lane >> 5, l5 = lane & 31;
+        const int u1 = u1a + half;
         const int p = i + 1 + u1;
-        const int u2 = (m - u1) - lane; // lane t holds q = q0 + t, q0 = j - 1 - (m - u1)
-        bool big = false, nz = false;
-        if (u2 >= 0 && !(u1 == 0 && u2 == 0)) {
-          const int q = j - 1 - u2;
-          int type2 = ra_bp(lds, s[p], s[q]);
-          const double as = EM(a_stem, p - 1, q);
-          if (type2 != 0 && as != kNegInf) {
-            type2 = ra_rtype(type2);
-            const double e = bs + ra_loop_energy(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
-            nz = e > -708.39641853226408; // ra_expd(e) != 0
-            big = e >= 89.0;
-          }
-        }
-        const unsigned long long nzmask = __ballot(nz);
-        if (nzmask == 0) continue;
-        const unsigned long long bigmask = __ballot(big);
-        const int kl1 = p - delta; // left range [i+1, p-delta], shared by all q of this p
-        const int q0 = j - 1 - (m - u1);
+        const int u2 = (m - u1) - l5; // lane t of a half holds q = q0 + t, q0 = j - 1 - (m - u1)
+        const bool in = u1 <= m && u2 >= 0 && !(u1 == 0 && u2 == 0);
+        const int pp = in ? p : i + 1, q = in ? j - 1 - u2 : j - 1; // (a lane without a tuple reads inside the window all the same)
+        const int type2raw = ra_bp(lds, s[pp], s[q]);
+        const double as = EM(a_stem, pp - 1, q);
+        const double z = ra_loop_energy_bf(lds, c.big, type, ra_rtype(type2raw), in ? u1 : 0, in ? u2 : 0, bi1, bj1, s[pp - 1], s[q + 1]);
+        const double e = bs + z + as;
+        const bool ok = in && type2raw != 0 && as != kNegInf;
+        const bool nz = ok && e > -708.39641853226408; // ra_expd(e) != 0
+        const bool big = ok && e >= 89.0;
+        const unsigned long long nzall = __ballot(nz);
+        if (nzall == 0) continue;
+        const unsigned long long bigall = __ballot(big);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int k = kb + ((lane - kb) & 63) + 64 * h;
-          unsigned add = 0;
-          if (k <= kl1) add |= (k == kl1 ? 2u : 8u) | (bigmask ? (k == kl1 ? 1u : 4u) : 0u);
-          if (k <= kr1) { // right ranges [q+1, j-delta]: the tuples with q <= k - 1, i.e. lanes t < k - q0
-            const int nl = k - q0;
-            if (nl > 0) {
-              const unsigned long long below = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
-              if (nzmask & below) add |= (k == kr1 ? 2u : 8u) | ((bigmask & below) ? (k == kr1 ? 1u : 4u) : 0u);
+        for (int r = 0; r < 2; r++) { // the two rows of this pass
+          const unsigned long long nzmask = (nzall >> (32 * r)) & 0xFFFFFFFFull, bigmask = (bigall >> (32 * r)) & 0xFFFFFFFFull;
+          if (nzmask == 0) continue;
+          const int ru1 = u1a + r;
+          const int kl1 = i + 1 + ru1 - delta; // left range [i+1, p-delta], shared by all q of this p
+          const int q0 = j - 1 - (m - ru1);
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int k = kb + ((lane - kb) & 63) + 64 * h;
+            unsigned add = 0;
+            if (k <= kl1) add |= (k == kl1 ? 2u : 8u) | (bigmask ? (k == kl1 ? 1u : 4u) : 0u);
+            if (k <= kr1) { // right ranges [q+1, j-delta]: the tuples with q <= k - 1, i.e. lanes t < k - q0
+              const int nl = k - q0;
+              if (nl > 0) {
+                const unsigned long long below = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+                if (nzmask & below) add |= (k == kr1 ? 2u : 8u) | ((bigmask & below) ? (k == kr1 ? 1u : 4u) : 0u);
+              }
             }
+            if ((k >> 6) & 1) f1 |= add;
+            else f0 |= add;
           }
-          if ((k >> 6) & 1) f1 |= add;
-          else f0 |= add;
         }
       }
     }
