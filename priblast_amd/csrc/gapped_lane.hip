@@ -30,9 +30,10 @@
 // 256 VGPRs and 38 KB of LDS per wavefront one wavefront per SIMD is resident, and its time is the sum of its
 // LDS / table / L2 latencies (time scaled 1 : 1.6 : 2.7 with 4 : 3 : 2 wavefronts per CU).  With the vote the
 // instruction count halves and the wall time doubles - fewer lanes advance per iteration while the latency per
-// iteration stays.  What it needs to pay off: >= 4 wavefronts per SIMD (<= 128 VGPRs: a leaner change of
-// direction; the cell lists pooled per wavefront in 8-cell chunks: ~8 KB of LDS), the small energy tables in LDS,
-// and a hand-over of its state to tier 0 for the 20 % of the hits that outgrow it (today they start again).
+// iteration stays.  Pooling the cell lists per wavefront to get to 4 wavefronts per SIMD was tried and reverted
+// (the pool that fits is too small for 64 live lists: 53 % of the hits complete, 201 spilled registers): the LDS
+// that 64 directions need allows two wavefronts per SIMD, which is not enough.  Kept as the reference point for a
+// per-hit state that is smaller than 12 bytes per cell.
 // A direction that outgrows the capacities (kD anti-diagonals, kR cells) is left to the LDS tiers of
 // gapped_lds.hip: the hit is flagged, and if its first direction was completed here that result is
 // handed over (kResumeMark) exactly as between those tiers.  Results are bit-identical to them
