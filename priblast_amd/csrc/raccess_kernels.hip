@@ -130,6 +130,22 @@ __device__ __forceinline__ uint32_t rowmask_window(const RowMasks &r, int start,
   return width >= 32 ? w : (w & ((1u << width) - 1));
 }
 
+// lane `l` (wave-uniform) of a double, whatever the execution mask: two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// the value the lane that owns cell `d` holds, for cells laid out d = dtop - lane over two passes (dtop = dmax, dmax - 64)
+__device__ __forceinline__ double cell_value_desc(const double (&reg)[2], int dmax, int d) {
+  const int l = dmax - d; // 0 .. 127
+  return l < 64 ? readlane_f64(reg[0], l) : readlane_f64(reg[1], l - 64);
+}
+
+// the same for values laid out one per lane in ascending order over two passes (index 0 .. 127)
+__device__ __forceinline__ double lane_value_asc(const double (&reg)[2], int idx) {
+  return idx < 64 ? readlane_f64(reg[0], idx) : readlane_f64(reg[1], idx - 64);
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -170,8 +186,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
     if (lane == 0) rowmask_clear(rm, j - 2); // the row that gets its first cell in column j + 1
 
     // phase 1: Alpha_stem (raccess.cpp:102-129) and Alpha_multi2 (:145-162): both need only
-    // column j-1 and the cell itself.
-    for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+    // column j-1 and the cell itself.  Also, per cell, the term it contributes to Alpha_outer[j] (:230-241),
+    // kept in a register for the chain of phase 3.
+    double to_reg[2] = {kNegInf, kNegInf}, mb_reg[2] = {kNegInf, kNegInf};
+    int pass = 0;
+    for (int dtop = dmax; dtop >= kTurn; dtop -= kWave, pass++) {
       const int d = dtop - lane;
       if (d < kTurn) continue;
       const int i = j - d;
@@ -197,8 +216,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
       double temp = 0;
       bool flag = false;
       if (type != 0 && stem != kNegInf) {
-        temp = stem + MLintern + dangle_energy(lds, v, type, i, j);
+        const double dng = dangle_energy(lds, v, type, i, j);
+        temp = stem + MLintern + dng;
         flag = true;
+        const double x = stem + dng; // (:235-236)
+        if (pass == 0) to_reg[0] = x + ao[i];
+        else to_reg[1] = x + ao[i];
       }
       const double prev = EM(a_multi2, i, j - 1);
       double m2;
@@ -214,20 +237,34 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
     RA_PROF(1);
 
     // phase 2: Alpha_multibif (:131-143) then Alpha_multi1 (:164-175)
-    for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+    pass = 0;
+    for (int dtop = dmax; dtop >= kTurn; dtop -= kWave, pass++) {
       const int d = dtop - lane;
-      if (d < kTurn) continue;
-      const int i = j - d;
+      const bool cell = d >= kTurn;
+      const int i = cell ? j - d : j - kTurn;
       double temp = 0;
       bool flag = false;
-      for (int t = 1; t < d; t++) { // k = i + t
-        const double m1 = EM(a_multi1, i, i + t), m2 = EM(a_multi2, i + t, j);
-        if (m1 != kNegInf && m2 != kNegInf) {
-          temp = flag ? ra_lse(lds, temp, m1 + m2) : m1 + m2;
-          flag = true;
+      // (operands of eight terms fetched together, then folded in order: k = i + t, t = 1 .. d - 1)
+      for (int t0 = 1; t0 < dtop; t0 += kRaAhead) {
+        double vs[kRaAhead];
+#pragma unroll
+        for (int b = 0; b < kRaAhead; b++) {
+          const bool in = cell && t0 + b < d;
+          const int t = in ? t0 + b : 1; // (a lane without a term reads one of its own)
+          const double m1 = EM(a_multi1, i, i + t), m2 = EM(a_multi2, i + t, j);
+          vs[b] = (in && m1 != kNegInf && m2 != kNegInf) ? m1 + m2 : kNegInf;
         }
+#pragma unroll
+        for (int b = 0; b < kRaAhead; b++)
+          if (vs[b] != kNegInf) {
+            temp = flag ? ra_lse(lds, temp, vs[b]) : vs[b];
+            flag = true;
+          }
       }
+      if (!cell) continue;
       const double mb = flag ? temp : kNegInf;
+      if (pass == 0) mb_reg[0] = mb;
+      else mb_reg[1] = mb;
       EM(a_multibif, i, j) = mb;
       const double m2 = EM(a_multi2, i, j);
       double m1;
@@ -240,34 +277,29 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
     wave_sync();
     RA_PROF(2);
 
-    // phase 3, two serial chains on two lanes: Alpha_multi (:177-191), i descending, and
-    // Alpha_outer[j] (:230-241), p ascending.
-    if (lane == 0) {
-      double prev = kNegInf; // Alpha_multi[i+1][..] of the first cell (d = 3) is never written
-      for (int d = kTurn; d <= dmax; d++) {
-        const int i = j - d;
-        const double mb = EM(a_multibif, i, j);
-        double m;
-        if (prev != kNegInf) {
-          m = prev + MLbase;
-          if (mb != kNegInf) m = ra_lse(lds, m, mb);
-        } else {
-          m = mb;
-        }
-        EM(a_multi, i, j) = m;
-        prev = m;
-      }
-    } else if (lane == 1) {
-      double temp = ao[j - 1];
-      for (int p = j - dmax; p < j; p++) {
-        const double st = EM(a_stem, p, j);
-        if (st != kNegInf) {
-          const int type = ra_bp(lds, s[p + 1], s[j]);
-          const double x = st + dangle_energy(lds, v, type, p, j);
-          temp = ra_lse(lds, temp, x + ao[p]);
+    // phase 3, two serial chains in ONE instruction stream on lanes 0 and 1: Alpha_multi (:177-191), i descending
+    // (d ascending), and Alpha_outer[j] (:230-241), p ascending (d descending).  A step's inputs come from the
+    // registers of the lanes that computed them (v_readlane), not through memory, so a step is one logsumexp.
+    {
+      const bool l0 = lane == 0;
+      double acc = l0 ? kNegInf : ao[j - 1]; // lane 0: Alpha_multi of the previous cell (none before d = 3); lane 1: the running sum
+      for (int k = 0; k + kTurn <= dmax; k++) {
+        const int d0 = kTurn + k, d1 = dmax - k;
+        const double mb = cell_value_desc(mb_reg, dmax, d0), to = cell_value_desc(to_reg, dmax, d1);
+        if (lane < 2) {
+          const double term = l0 ? mb : to;
+          const double base = l0 ? acc + MLbase : acc;
+          const double r = ra_lse(lds, base, term);
+          if (l0) {
+            const double m = acc != kNegInf ? (mb != kNegInf ? r : base) : mb;
+            EM(a_multi, j - d0, j) = m;
+            acc = m;
+          } else if (to != kNegInf) {
+            acc = r;
+          }
         }
       }
-      ao[j] = temp;
+      if (lane == 1) ao[j] = acc;
     }
     wave_sync();
     RA_PROF(3);
@@ -468,51 +500,73 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
 
     // phase A: Beta_stemend (:278-279), copy from column q+1
     if (use_masks && lane == 0) rowmask_clear(rm, q - W); // the row whose first cell comes in column q - 1 (spans >= W never exist)
-    if (q != L) {
-      for (int dbot = kTurn; dbot <= dmax; dbot += kWave) {
+    // Also, in registers for the chains of phase B: per cell the term it contributes to Beta_multi (:296-300), and
+    // - one per lane, p' = q + lane (+ 64) - the terms of Beta_outer[q - 1] (:262-269).
+    double xb_reg[2] = {kNegInf, kNegInf}, tob_reg[2] = {kNegInf, kNegInf};
+    const int pend_o = imin(q + W, L); // Beta_outer[q - 1] sums p' = q .. pend_o
+    {
+      int pass = 0;
+      for (int dbot = kTurn; dbot <= dmax; dbot += kWave, pass++) {
         const int d = dbot + lane;
-        if (d > dmax) continue;
+        if (q == L || d > dmax) continue;
         const int p = q - d;
         if (p != 0) {
           const double se = d >= W ? kNegInf : EM(b_stem, p - 1, q + 1);
           EM(b_stemend, p, q) = se;
           if (use_masks && se != kNegInf) rowmask_set(rm, p, d);
+          if (se != kNegInf) {
+            const int tt = ra_rtype(ra_bp(lds, s[p], s[q + 1]));
+            const double x = se + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + s[p + 1]] +
+                             lds.small[SL::kDangle5 + tt * 5 + s[q]];
+            if (pass == 0) xb_reg[0] = x;
+            else xb_reg[1] = x;
+          }
+        }
+      }
+      for (pass = 0; pass < 2; pass++) {
+        const int pp = q + lane + 64 * pass;
+        if (pp > pend_o) continue;
+        const int i = q - 1;
+        const double st = EM(a_stem, i, pp);
+        if (st != kNegInf) {
+          const int type = ra_bp(lds, s[i + 1], s[pp]);
+          const double x = st + dangle_energy(lds, v, type, i, pp);
+          if (pass == 0) tob_reg[0] = x + bo[pp];
+          else tob_reg[1] = x + bo[pp];
         }
       }
     }
     wave_sync();
     RA_PROF(8);
 
-    // phase B, serial chains: Beta_multi (:281-308), p ascending, on lane 0;
-    // Beta_outer[q-1] on lane 1.
-    if (lane == 0) {
-      if (q != L) {
-        for (int d = dmax; d >= kTurn; d--) {
-          const int p = q - d;
-          if (p == 0) continue;
-          double temp = 0;
-          bool flag = false;
-          if (d + 1 <= W + 1) {
-            const double pm = EM(b_multi, p - 1, q);
-            if (pm != kNegInf) {
-              temp = pm + MLbase;
-              flag = true;
+    // phase B, two serial chains in one instruction stream (see k_inside's phase 3): Beta_multi (:281-308), p
+    // ascending (d descending), on lane 0; Beta_outer[q - 1] (:260-271), p' ascending, on lane 1; inputs by v_readlane.
+    {
+      const bool l0 = lane == 0;
+      const int k0n = q != L ? dmax - kTurn + 1 : 0, k1n = pend_o - q + 1;
+      double acc = l0 ? kNegInf : bo[q]; // lane 0: Beta_multi of the previous cell; lane 1: the running sum
+      for (int k = 0; k < imax(k0n, k1n); k++) {
+        const int d0 = dmax - k;
+        const double xb = k < k0n ? lane_value_asc(xb_reg, d0 - kTurn) : kNegInf;
+        const double to = k < k1n ? lane_value_asc(tob_reg, k) : kNegInf;
+        if (lane < 2) {
+          const double term = l0 ? xb : to;
+          const double base = l0 ? acc + MLbase : acc;
+          const double r = ra_lse(lds, base, term);
+          if (l0) {
+            const int p = q - d0;
+            if (k < k0n && p != 0) {
+              const bool flag = d0 + 1 <= W + 1 && acc != kNegInf; // (Beta_multi[p - 1][q - p + 1] exists)
+              const double temp = xb != kNegInf ? (flag ? r : xb) : (flag ? base : kNegInf);
+              EM(b_multi, p, q) = temp;
+              acc = temp;
             }
+          } else if (to != kNegInf) {
+            acc = r;
           }
-          const int tt = ra_rtype(ra_bp(lds, s[p], s[q + 1]));
-          const double se = EM(b_stemend, p, q);
-          if (se != kNegInf) {
-            const double x = se + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + s[p + 1]] +
-                             lds.small[SL::kDangle5 + tt * 5 + s[q]];
-            temp = flag ? ra_lse(lds, temp, x) : x;
-          } else if (!flag) {
-            temp = kNegInf;
-          }
-          EM(b_multi, p, q) = temp;
         }
       }
-    } else if (lane == 1) {
-      beta_outer_at(q - 1);
+      if (lane == 1) bo[q - 1] = acc;
     }
     wave_sync();
     RA_PROF(9);
@@ -527,12 +581,22 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
         double temp = 0;
         bool flag = false;
         const int kend = imin(L, p + W);
-        for (int k = q + 1; k <= kend; k++) {
-          const double bb = EM(b_multibif, p, k), m2 = EM(a_multi2, q, k);
-          if (bb != kNegInf && m2 != kNegInf) {
-            temp = flag ? ra_lse(lds, temp, bb + m2) : bb + m2;
-            flag = true;
+        // (operands of eight terms fetched together, then folded in order)
+        for (int k0 = q + 1; k0 <= kend; k0 += kRaAhead) {
+          double vs[kRaAhead];
+#pragma unroll
+          for (int b = 0; b < kRaAhead; b++) {
+            const bool in = k0 + b <= kend;
+            const int k = in ? k0 + b : q + 1;
+            const double bb = EM(b_multibif, p, k), m2 = EM(a_multi2, q, k);
+            vs[b] = (in && bb != kNegInf && m2 != kNegInf) ? bb + m2 : kNegInf;
           }
+#pragma unroll
+          for (int b = 0; b < kRaAhead; b++)
+            if (vs[b] != kNegInf) {
+              temp = flag ? ra_lse(lds, temp, vs[b]) : vs[b];
+              flag = true;
+            }
         }
         const double m1 = flag ? temp : kNegInf;
         EM(b_multi1, p, q) = m1;
@@ -566,12 +630,21 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
             flag = true;
           }
         }
-        for (int k = imax(0, q - W); k < p; k++) {
-          const double bb = EM(b_multibif, k, q), a1 = SM(a_multi1t, k, p);
-          if (bb != kNegInf && a1 != kNegInf) {
-            temp = flag ? ra_lse(lds, temp, bb + a1) : bb + a1;
-            flag = true;
+        for (int k0 = imax(0, q - W); k0 < p; k0 += kRaAhead) { // (eight terms' operands together, as in phase C)
+          double vs[kRaAhead];
+#pragma unroll
+          for (int b = 0; b < kRaAhead; b++) {
+            const bool in = k0 + b < p;
+            const int k = in ? k0 + b : p - 1; // (p >= 1 here)
+            const double bb = EM(b_multibif, k, q), a1 = SM(a_multi1t, k, p);
+            vs[b] = (in && bb != kNegInf && a1 != kNegInf) ? bb + a1 : kNegInf;
           }
+#pragma unroll
+          for (int b = 0; b < kRaAhead; b++)
+            if (vs[b] != kNegInf) {
+              temp = flag ? ra_lse(lds, temp, vs[b]) : vs[b];
+              flag = true;
+            }
         }
         EM(b_multi2, p, q) = flag ? temp : kNegInf;
       }
