@@ -323,29 +323,24 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
         int u1 = -1;
         uint32_t wbits = 0; // the terms left in row u1: bit b = span span_lo + b
         bool more = m >= 0;
-        while (__ballot(more) != 0) {
-          // (1) the next eight terms of this lane: integer work and the row masks in LDS only
+        // One batch = the next eight terms of this lane, as values: (1) which terms - integer work and the row masks in
+        // LDS, without a branch: a step that finds its row used up moves on ONE row and may come back empty-handed;
+        // (2) their band entries and sequence codes, all fetched together (a lane without a term reads its own cell);
+        // (3) their values - the table look-ups are independent of each other.
+        auto next_batch = [&](double (&xs)[kRaAhead]) {
           int su1[kRaAhead], sspan[kRaAhead];
 #pragma unroll
           for (int t = 0; t < kRaAhead; t++) {
-            int span = -1;
-            if (more) {
-              while (wbits == 0 && u1 < m) { // next row with a term
-                u1++;
-                wbits = rowmask_window(rm, i + u1, span_lo, d - u1 - (u1 == 0 ? 1 : 0)); // (p, q) == (i, j) is excluded (:207)
-              }
-              if (wbits != 0) {
-                span = span_lo + __builtin_ctz(wbits);
-                wbits &= wbits - 1;
-              } else {
-                more = false;
-              }
-            }
-            su1[t] = span >= 0 ? u1 : -1;
-            sspan[t] = span;
+            const bool adv = more && wbits == 0 && u1 < m;
+            u1 += adv ? 1 : 0;
+            const uint32_t wnew = rowmask_window(rm, i + (u1 < 0 ? 0 : u1), span_lo, d - u1 - (u1 == 0 ? 1 : 0)); // (p, q) == (i, j) is excluded (:207)
+            wbits = adv ? wnew : wbits;
+            const bool has = more && wbits != 0;
+            sspan[t] = span_lo + __builtin_ctz(wbits | 0x80000000u);
+            su1[t] = has ? u1 : -1;
+            wbits = has ? (wbits & (wbits - 1)) : wbits;
+            more = more && (wbits != 0 || u1 < m);
           }
-          RA_PROF(19);
-          // (2) their band entries and sequence codes, all fetched together (a lane without a term reads its own cell)
           double sts[kRaAhead];
           int su2[kRaAhead], sq[kRaAhead], sq1[kRaAhead], sp0[kRaAhead], sp1[kRaAhead];
 #pragma unroll
@@ -359,25 +354,30 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
             sp0[t] = s[p];
             sp1[t] = s[p + 1];
           }
-          RA_PROF(20);
-          // the terms' values first (their table look-ups are independent of each other), then the fold: its
-          // chain of dependent logsumexp is what a column costs, nothing else should sit on it
-          double xs[kRaAhead];
 #pragma unroll
           for (int t = 0; t < kRaAhead; t++) {
             const int type2 = ra_rtype(ra_bp(lds, sp1[t], sq[t])); // (not 0 where the stem exists)
             const double z = ra_loop_energy_bf(lds, c.big, type, type2, su1[t] < 0 ? 0 : su1[t], su2[t], bi1, bj, sp0[t], sq1[t]);
             xs[t] = (su1[t] >= 0 && sts[t] != kNegInf && type2 != 0) ? sts[t] + z : kNegInf;
           }
-          RA_PROF(21);
+        };
+        // The fold - a chain of dependent logsumexp, what a column costs - runs one batch behind: the next batch is
+        // prepared in the same stretch of straight-line code, so its loads and look-ups fill the chain's stalls.
+        double xs[kRaAhead];
+        bool pending = __ballot(more) != 0;
+        if (pending) next_batch(xs);
+        while (pending) {
+          double xn[kRaAhead];
+          const bool again = __ballot(more) != 0;
+          if (again) next_batch(xn);
 #pragma unroll
           for (int t = 0; t < kRaAhead; t++) {
-            RA_COUNT(18, __popcll(__ballot(xs[t] != kNegInf)));
-            RA_COUNT(17, (xs[t] != kNegInf && (xs[t] < temp - 17.4 || temp < xs[t] - 17.4)) ? 1 : 0);
-            if (xs[t] != kNegInf) temp = ra_lse(lds, temp, xs[t]);
+            const double r = ra_lse(lds, temp, xs[t]);
+            temp = xs[t] != kNegInf ? r : temp;
           }
-          RA_COUNT(16, 1);
-          RA_PROF(22);
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) xs[t] = xn[t];
+          pending = again;
         }
         if (cell) {
           double out = kNegInf;
@@ -670,27 +670,23 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
         uint32_t wbits = 0;
         int span0 = 0; // span of bit 0 of wbits
         bool more = t2raw != 0 && u1 > 0;
-        while (__ballot(more) != 0) {
+        // (as in k_inside's phase 4: which terms, without a branch; fetch; values - then the fold one batch behind)
+        auto next_batch = [&](double (&xs)[kRaAhead]) {
           int su1[kRaAhead], sspan[kRaAhead];
 #pragma unroll
           for (int t = 0; t < kRaAhead; t++) {
-            int span = -1;
-            if (more) {
-              while (wbits == 0 && u1 > 0) { // next row with a term
-                u1--;
-                const int u2max = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - d - u1);
-                span0 = d + u1 + (u1 == 0 ? 1 : 0); // (i, j) == (p, q) is excluded (:377)
-                wbits = rowmask_window(rm, p - u1, span0, d + u1 + u2max);
-              }
-              if (wbits != 0) {
-                span = span0 + __builtin_ctz(wbits);
-                wbits &= wbits - 1;
-              } else {
-                more = false;
-              }
-            }
-            su1[t] = span >= 0 ? u1 : -1;
-            sspan[t] = span;
+            const bool adv = more && wbits == 0 && u1 > 0;
+            u1 -= adv ? 1 : 0;
+            const int u2max = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - d - u1);
+            const int s0 = d + u1 + (u1 == 0 ? 1 : 0); // (i, j) == (p, q) is excluded (:377)
+            const uint32_t wnew = rowmask_window(rm, p - u1, s0, d + u1 + u2max);
+            wbits = adv ? wnew : wbits;
+            span0 = adv ? s0 : span0;
+            const bool has = more && wbits != 0;
+            sspan[t] = span0 + __builtin_ctz(wbits | 0x80000000u);
+            su1[t] = has ? u1 : -1;
+            wbits = has ? (wbits & (wbits - 1)) : wbits;
+            more = more && (wbits != 0 || u1 > 0);
           }
           double ses[kRaAhead];
           int su2[kRaAhead], sj[kRaAhead], sj1[kRaAhead], si0[kRaAhead], si1[kRaAhead];
@@ -705,16 +701,28 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
             si0[t] = s[i];
             si1[t] = s[i + 1];
           }
-          double xs[kRaAhead];
 #pragma unroll
           for (int t = 0; t < kRaAhead; t++) {
             const int type = ra_bp(lds, si0[t], sj1[t]);
             const double z = ra_loop_energy_bf(lds, c.big, type, type2, su1[t] < 0 ? 0 : su1[t], su2[t], si1[t], sj[t], bp0, bq1);
             xs[t] = (su1[t] >= 0 && ses[t] != kNegInf && type != 0) ? ses[t] + z : kNegInf;
           }
+        };
+        double xs[kRaAhead];
+        bool pending = __ballot(more) != 0;
+        if (pending) next_batch(xs);
+        while (pending) {
+          double xn[kRaAhead];
+          const bool again = __ballot(more) != 0;
+          if (again) next_batch(xn);
 #pragma unroll
-          for (int t = 0; t < kRaAhead; t++)
-            if (xs[t] != kNegInf) temp = ra_lse(lds, temp, xs[t]);
+          for (int t = 0; t < kRaAhead; t++) {
+            const double r = ra_lse(lds, temp, xs[t]);
+            temp = xs[t] != kNegInf ? r : temp;
+          }
+#pragma unroll
+          for (int t = 0; t < kRaAhead; t++) xs[t] = xn[t];
+          pending = again;
         }
       } else {
         // (spans beyond the row masks: every (u1, u2) term of the window is enumerated wave-uniformly)
@@ -924,56 +932,96 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
   for (int i = 1; i < L - kTurn - 2; i++) {
     const int kb = i + 1; // smallest position this and later i can touch
     const int jend = imin(i + W, L);
-    for (int j = i + kTurn + 3; j <= jend; j++) {
-      const int type = ra_bp(lds, s[i], s[j]);
-      if (type == 0) continue;
-      const double bs = EM(b_stemend, i, j - 1);
-      if (bs == kNegInf) continue;
-      const int D = j - i;
-      const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
-      const int bi1 = s[i + 1], bj1 = s[j - 1];
-      const int kr1 = j - delta;
-      // two rows (u1, u1 + 1) per pass, 32 lanes each: the flags are ORs, so the order of the tuples does not matter;
-      // straight-line evaluation (branch-free loop energy: the lanes' loops are of different classes)
-      for (int u1a = 0; u1a <= m; u1a += 2) {
-        const int half = lane >> 5, l5 = lane & 31;
-        const int u1 = u1a + half;
-        const int p = i + 1 + u1;
-        const int u2 = (m - u1) - l5; // lane t of a half holds q = q0 + t, q0 = j - 1 - (m - u1)
-        const bool in = u1 <= m && u2 >= 0 && !(u1 == 0 && u2 == 0);
-        const int pp = in ? p : i + 1, q = in ? j - 1 - u2 : j - 1; // (a lane without a tuple reads inside the window all the same)
-        const int type2raw = ra_bp(lds, s[pp], s[q]);
-        const double as = EM(a_stem, pp - 1, q);
-        const double z = ra_loop_energy_bf(lds, c.big, type, ra_rtype(type2raw), in ? u1 : 0, in ? u2 : 0, bi1, bj1, s[pp - 1], s[q + 1]);
-        const double e = bs + z + as;
-        const bool ok = in && type2raw != 0 && as != kNegInf;
-        const bool nz = ok && e > -708.39641853226408; // ra_expd(e) != 0
-        const bool big = ok && e >= 89.0;
-        const unsigned long long nzall = __ballot(nz);
-        if (nzall == 0) continue;
-        const unsigned long long bigall = __ballot(big);
+    // the closing pairs (i, j) of this i that exist, found for all j at once: lane t looks at j = jb + t
+    for (int jb = i + kTurn + 3; jb <= jend; jb += kWave) {
+      const int jl = jb + lane;
+      const int typ_l = jl <= jend ? ra_bp(lds, s[i], s[jl]) : 0;
+      const double bs_l = typ_l != 0 ? EM(b_stemend, i, jl - 1) : kNegInf;
+      unsigned long long jmask = __ballot(typ_l != 0 && bs_l != kNegInf);
+      while (jmask) {
+        const int jt = __builtin_ctzll(jmask);
+        jmask &= jmask - 1;
+        const int j = jb + jt;
+        const int type = __builtin_amdgcn_readlane(typ_l, jt);
+        const double bs = readlane_f64(bs_l, jt);
+        const int D = j - i;
+        const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
+        const int bi1 = s[i + 1], bj1 = s[j - 1];
+        const int kr1 = j - delta;
+        // The tuples (u1, u2), u2 = 0 .. m - u1, of row u1 make m - u1 + 1 lanes; rows a and m + 1 - a together make
+        // m + 1 <= 31, so half a wavefront takes two rows and a pass four (row 0 and - m odd - the middle row go alone).
+        // The flags are ORs, so only two things matter about a pass: which rows have a non-zero / a big term (the left
+        // ranges [i + 1, p - delta] depend on the row only) and which columns q have one (the right ranges [q + 1,
+        // j - delta] on the column only).  Both are collected from the ballots with scalar instructions; the positions
+        // are updated once per (i, j), not once per row.
+        unsigned long long col_nz = 0, col_big = 0; // bit = q - (j - 1 - m)
+        unsigned row_nz = 0, row_big = 0;           // bit = u1
+        const int nslots = 1 + (m + 1) / 2;         // (0), (1, m), (2, m - 1), ...
+        for (int s0 = 0; s0 < nslots; s0 += 2) {
+          const int half = lane >> 5, l5 = lane & 31;
+          const int slot = s0 + half;
+          const int ra_ = slot, rb_ = slot == 0 ? -1 : m + 1 - slot; // the slot's rows (rb_ <= ra_: none / the same row)
+          const int na = slot < nslots ? m - ra_ + 1 : 0, nb = (slot < nslots && rb_ > ra_) ? m - rb_ + 1 : 0;
+          const bool in_a = l5 < na, in_b = !in_a && l5 < na + nb;
+          const int u1 = in_a ? ra_ : rb_, t5 = in_a ? l5 : l5 - na;
+          const int u2 = (m - u1) - t5; // lane t of a row holds q = q0 + t, q0 = j - 1 - (m - u1)
+          const bool in = (in_a || in_b) && !(u1 == 0 && u2 == 0);
+          const int pp = in ? i + 1 + u1 : i + 1, q = in ? j - 1 - u2 : j - 1; // (a lane without a tuple reads inside the window)
+          const int type2raw = ra_bp(lds, s[pp], s[q]);
+          const double as = EM(a_stem, pp - 1, q);
+          const double z = ra_loop_energy_bf(lds, c.big, type, ra_rtype(type2raw), in ? u1 : 0, in ? u2 : 0, bi1, bj1, s[pp - 1], s[q + 1]);
+          const double e = bs + z + as;
+          const bool ok = in && type2raw != 0 && as != kNegInf;
+          const bool nz = ok && e > -708.39641853226408; // ra_expd(e) != 0
+          const bool big = ok && e >= 89.0;
+          const unsigned long long nzall = __ballot(nz);
+          if (nzall == 0) continue;
+          const unsigned long long bigall = __ballot(big);
 #pragma unroll
-        for (int r = 0; r < 2; r++) { // the two rows of this pass
-          const unsigned long long nzmask = (nzall >> (32 * r)) & 0xFFFFFFFFull, bigmask = (bigall >> (32 * r)) & 0xFFFFFFFFull;
-          if (nzmask == 0) continue;
-          const int ru1 = u1a + r;
-          const int kl1 = i + 1 + ru1 - delta; // left range [i+1, p-delta], shared by all q of this p
-          const int q0 = j - 1 - (m - ru1);
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const int k = kb + ((lane - kb) & 63) + 64 * h;
-            unsigned add = 0;
-            if (k <= kl1) add |= (k == kl1 ? 2u : 8u) | (bigmask ? (k == kl1 ? 1u : 4u) : 0u);
-            if (k <= kr1) { // right ranges [q+1, j-delta]: the tuples with q <= k - 1, i.e. lanes t < k - q0
-              const int nl = k - q0;
-              if (nl > 0) {
-                const unsigned long long below = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
-                if (nzmask & below) add |= (k == kr1 ? 2u : 8u) | ((bigmask & below) ? (k == kr1 ? 1u : 4u) : 0u);
-              }
+          for (int h = 0; h < 2; h++) { // (wave-uniform: scalar instructions)
+            const int sl = s0 + h;
+            if (sl >= nslots) continue;
+            const int a_ = sl, b_ = sl == 0 ? -1 : m + 1 - sl;
+            const int n_a = m - a_ + 1, n_b = b_ > a_ ? m - b_ + 1 : 0;
+            const unsigned hn = (unsigned)(nzall >> (32 * h)), hb = (unsigned)(bigall >> (32 * h));
+            const unsigned an = hn & ((n_a >= 32 ? 0u : (1u << n_a)) - 1u), ab = hb & ((n_a >= 32 ? 0u : (1u << n_a)) - 1u);
+            col_nz |= (unsigned long long)an << a_;
+            col_big |= (unsigned long long)ab << a_;
+            row_nz |= (an != 0 ? 1u : 0u) << a_;
+            row_big |= (ab != 0 ? 1u : 0u) << a_;
+            if (n_b > 0) {
+              const unsigned bn = (hn >> n_a) & ((1u << n_b) - 1u), bb = (hb >> n_a) & ((1u << n_b) - 1u);
+              col_nz |= (unsigned long long)bn << b_;
+              col_big |= (unsigned long long)bb << b_;
+              row_nz |= (bn != 0 ? 1u : 0u) << b_;
+              row_big |= (bb != 0 ? 1u : 0u) << b_;
             }
-            if ((k >> 6) & 1) f1 |= add;
-            else f0 |= add;
           }
+        }
+        if (row_nz == 0) continue;
+        // the positions: left ranges end at p - delta = i + 1 + u1 - delta, right ranges at j - delta
+        const int qbase = j - 1 - m;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int k = kb + ((lane - kb) & 63) + 64 * h;
+          unsigned add = 0;
+          const int ustar = k - (i + 1 - delta); // the row whose left range ends at k
+          if (ustar >= 0 && ustar <= m) {
+            if ((row_nz >> ustar) & 1) add |= 2u | (((row_big >> ustar) & 1) ? 1u : 0u);
+          }
+          if (ustar < m) { // rows above: k lies inside their left ranges
+            const int sh = ustar < 0 ? 0 : ustar + 1;
+            if (row_nz >> sh) add |= 8u | ((row_big >> sh) ? 4u : 0u);
+          }
+          if (k <= kr1) { // right ranges [q + 1, j - delta]: the tuples with q <= k - 1
+            const int nl = k - qbase;
+            if (nl > 0) {
+              const unsigned long long below = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+              if (col_nz & below) add |= (k == kr1 ? 2u : 8u) | ((col_big & below) ? (k == kr1 ? 1u : 4u) : 0u);
+            }
+          }
+          if ((k >> 6) & 1) f1 |= add;
+          else f0 |= add;
         }
       }
     }

@@ -33,8 +33,6 @@ def main():
     total = sum(buf[:16])
     for k, name in NAMES.items():
         print(f"  {name:34s} {buf[k] / 1e6:10.2f} Mcycles  {buf[k] / total * 100:5.1f} %   {buf[k] / L:10.0f} cycles per column")
-    print(f"  inside 4 per batch: iterate {buf[19] / max(buf[16], 1):.0f}, load {buf[20] / max(buf[16], 1):.0f}, evaluate {buf[21] / max(buf[16], 1):.0f}, fold {buf[22] / max(buf[16], 1):.0f} cycles")
-    print(f"  inside 4: batches per column {buf[16] / L:.1f}, folded terms per column (lane 0) {buf[18] / L:.0f}, of which more than 17.4 apart {buf[17] / L:.0f}")
 
 
 
