@@ -269,6 +269,8 @@ def main():
         lo, hi = pdist.batch_slice(k, rank, world, a.queries)
         t0 = time.perf_counter()
         qb = capi.QBatch(c, qseqs[lo:hi], db.repeat_flag)
+        if c is not ctx:  # prepared ahead: the seed DFS of the first page can run behind the current search as well
+            qb.seed_search_begin(db, 0, opts)
         t1 = time.perf_counter()
         qb.accessibility(db.W, db.delta)
         wall["qbatch (encode + SA + upload)"] += t1 - t0

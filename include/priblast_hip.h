@@ -143,6 +143,11 @@ int prb_qbatch_accessibility(prb_ctx *ctx, prb_qbatch *qb, int32_t maximal_span,
 /* copies of the per-query arrays (NULL pointers are skipped) */
 int prb_qbatch_get(prb_qbatch *qb, int32_t q, uint8_t *enc, int32_t *sa, float *acc, float *cond);
 int32_t prb_qbatch_length_unmasked(const prb_qbatch *qb, int32_t q);
+/* Optional: starts the seed search proper (the suffix-array DFS of SeedSearch::Run, seed_search.cpp:153-295; host
+ * threads) of the batch against `page` in the background and returns at once.  A later prb_search_page with the
+ * same database, page, -l and -e picks it up instead of starting its own - e.g. begun for the NEXT batch while
+ * this one is searched.  It needs neither the accessibilities nor the GPU. */
+int prb_qbatch_seed_search_begin(prb_ctx *ctx, prb_qbatch *qb, const prb_db *db, int32_t page, const prb_ris_opts *opts);
 
 /* ---- stages 3-5: seed search, ungapped and gapped extension for all queries of a batch
  * against one page.  last_stage: 1 = seeds, 2 = after ungapped extension + filter,

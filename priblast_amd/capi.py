@@ -74,6 +74,7 @@ SYMBOLS = {
     "prb_qbatch_get": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p]),
     "prb_qbatch_length_unmasked": (c_i32, [ctypes.c_void_p, c_i32]),
+    "prb_qbatch_seed_search_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i32, P(RisOpts)]),
     "prb_search_page": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i32, P(RisOpts), c_i32,
                                        P(ctypes.c_void_p)]),
     "prb_hitset_size": (c_i64, [ctypes.c_void_p]),
@@ -282,6 +283,11 @@ class QBatch:
 
     def length_unmasked(self, q):
         return lib().prb_qbatch_length_unmasked(self.h, q)
+
+    def seed_search_begin(self, db, page, opts=None):
+        """starts the seed DFS against `page` in the background; a later search_page with the same options uses it"""
+        o = opts or default_opts()
+        _check(lib().prb_qbatch_seed_search_begin(self.ctx.h, self.h, db.h, page, ctypes.byref(o)))
 
 
 class _HitSetOwner:

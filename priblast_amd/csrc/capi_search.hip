@@ -195,6 +195,29 @@ struct prb_db {
   std::vector<SeqTable> tabs; // per page: what the result lines print about its sequences
 };
 
+// The seed search proper of a batch against one page (SeedSearch::Run's DFS, seed_search.cpp:153-295): per query,
+// on host threads, in the background; a consumer waits for query q with wait_for(q).  It needs the encoded queries,
+// their suffix arrays and the page's k-mer table only - not the accessibilities - so it can be started as soon as a
+// batch exists (prb_qbatch_seed_search_begin), long before the batch is searched.
+struct SeedPlan {
+  const prb_db *db = nullptr;
+  int32_t page = 0, nq = 0, max_seed_length = 0;
+  double hybrid_threshold = 0;
+  std::vector<std::vector<SeedCandidate>> per_q;
+  std::vector<double> qpairs;
+  std::vector<int64_t> qrows, qents;
+  std::unique_ptr<std::atomic<int>[]> done;
+  std::atomic<int32_t> next_query{0}; // queries are handed out strictly in order: the consumer needs the first ones first
+  std::thread producer;
+  double dfs_ms = 0;
+  ~SeedPlan() {
+    if (producer.joinable()) producer.join();
+  }
+  void wait_for(int32_t q) const {
+    while (!done[q].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+};
+
 struct prb_qbatch {
   prb_ctx *ctx = nullptr;
   int32_t nq = 0, repeat_flag = 0;
@@ -207,6 +230,7 @@ struct prb_qbatch {
   bool have_acc = false;
   int32_t W = 0, delta = 0;
   QBatchDev view{};
+  std::unique_ptr<SeedPlan> plan; // a seed search started ahead of prb_search_page, if any
 };
 
 namespace prb {
@@ -680,6 +704,8 @@ int32_t prb_qbatch_length_unmasked(const prb_qbatch *qb, int32_t q) {
   if (!qb || q < 0 || q >= qb->nq) return -1;
   return qb->len_unmasked[q];
 }
+
+int prb_qbatch_seed_search_begin(prb_ctx *ctx, prb_qbatch *qb, const prb_db *db, int32_t page, const prb_ris_opts *opts);
 
 } // extern "C"
 
@@ -1262,7 +1288,69 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
 
 } // namespace prb
 
+namespace prb {
+static std::unique_ptr<SeedPlan> start_seed_plan(prb_ctx *ctx, const prb_qbatch *qb, const prb_db *db, int32_t page, int32_t max_seed_length,
+                                                 double hybrid_threshold) {
+  std::unique_ptr<SeedPlan> pl(new SeedPlan());
+  SeedPlan *P = pl.get();
+  const int32_t nq = qb->nq;
+  P->db = db;
+  P->page = page;
+  P->nq = nq;
+  P->max_seed_length = max_seed_length;
+  P->hybrid_threshold = hybrid_threshold;
+  P->per_q.resize((size_t)nq);
+  P->qpairs.assign((size_t)nq, 0);
+  P->qrows.assign((size_t)nq, 0);
+  P->qents.assign((size_t)nq, 0);
+  P->done.reset(new std::atomic<int>[(size_t)nq]);
+  for (int32_t q = 0; q < nq; q++) P->done[q].store(0, std::memory_order_relaxed);
+  const EnergyParams *params = &ctx->params;
+  const DbPage *pg = &db->pages[(size_t)page];
+  const int hash_size = db->hdr.hash_size, delta = db->hdr.min_accessible_length;
+  P->producer = std::thread([P, qb, params, pg, hash_size, delta, nq] {
+    const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel num_threads(host_threads(nq))
+    for (;;) {
+      const int32_t q = P->next_query.fetch_add(1, std::memory_order_relaxed);
+      if (q >= nq) break;
+      seed_dfs(*params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], *pg, hash_size, P->max_seed_length, delta,
+               P->hybrid_threshold, P->per_q[q]);
+      double pairs = 0;
+      int64_t rows = 0, ents = 0;
+      for (auto &c : P->per_q[q]) {
+        c.query = q;
+        pairs += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
+        rows += (int64_t)c.ep_db - c.sp_db + 1;
+        ents += (int64_t)c.ep_q - c.sp_q + 1;
+      }
+      P->qpairs[q] = pairs;
+      P->qrows[q] = rows;
+      P->qents[q] = ents;
+      P->done[q].store(1, std::memory_order_release);
+    }
+    P->dfs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  });
+  return pl;
+}
+} // namespace prb
+
 extern "C" {
+
+int prb_qbatch_seed_search_begin(prb_ctx *ctx, prb_qbatch *qb, const prb_db *db, int32_t page, const prb_ris_opts *opts) {
+  if (!ctx || !qb || !db || !opts || page < 0 || page >= (int32_t)db->pages.size() || opts->max_seed_length < 1 ||
+      opts->max_seed_length > 63 || qb->repeat_flag != db->hdr.repeat_flag) {
+    set_error("prb_qbatch_seed_search_begin: bad argument");
+    return PRB_ERR_ARG;
+  }
+  try {
+    qb->plan = start_seed_plan(ctx, qb, db, page, opts->max_seed_length, opts->hybrid_threshold); // (an unused earlier one is joined and dropped)
+  } catch (const std::exception &e) {
+    set_error(std::string("prb_qbatch_seed_search_begin: ") + e.what());
+    return PRB_ERR_NOMEM;
+  }
+  return PRB_OK;
+}
 
 int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, const prb_ris_opts *opts, int32_t last_stage,
                     prb_hitset **out) {
@@ -1287,7 +1375,6 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     return PRB_ERR_ARG;
   }
   PRB_HIP(hipSetDevice(ctx->device));
-  const DbPage &pg = db->pages[page];
   {
     // the page on the device (uploaded now unless it is resident or was prefetched), then - while it is searched -
     // the next page on the copy stream
@@ -1303,41 +1390,22 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   }
   // Seed search proper: DFS over the two suffix arrays, per query, on host threads.  It runs
   // in the background while the GPU already works on the first sub-batches: the consumer below
-  // only waits for the queries it is about to submit.
+  // only waits for the queries it is about to submit.  If the caller started it ahead
+  // (prb_qbatch_seed_search_begin with the same page and options), that one is used.
   const int32_t nq = qb->nq;
-  std::vector<std::vector<SeedCandidate>> per_q((size_t)nq);
-  std::vector<double> qpairs((size_t)nq, 0);
-  std::vector<int64_t> qrows((size_t)nq, 0), qents((size_t)nq, 0);
-  std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[(size_t)nq]);
-  for (int32_t q = 0; q < nq; q++) done[q].store(0, std::memory_order_relaxed);
-  const auto t_dfs0 = std::chrono::steady_clock::now();
-  double dfs_ms = 0;
-  std::atomic<int32_t> next_query{0}; // queries are handed out strictly in order: the consumer needs the first ones first
-  std::thread producer([&] {
-#pragma omp parallel num_threads(host_threads(nq))
-    for (;;) {
-      const int32_t q = next_query.fetch_add(1, std::memory_order_relaxed);
-      if (q >= nq) break;
-      seed_dfs(ctx->params, qb->enc.data() + qb->off[q], qb->len[q] + 1, qb->sa.data() + qb->off[q], pg, db->hdr.hash_size,
-               opts->max_seed_length, db->hdr.min_accessible_length, opts->hybrid_threshold, per_q[q]);
-      double pairs = 0;
-      int64_t rows = 0, ents = 0;
-      for (auto &c : per_q[q]) {
-        c.query = q;
-        pairs += (double)(c.ep_q - c.sp_q + 1) * (double)(c.ep_db - c.sp_db + 1);
-        rows += (int64_t)c.ep_db - c.sp_db + 1;
-        ents += (int64_t)c.ep_q - c.sp_q + 1;
-      }
-      qpairs[q] = pairs;
-      qrows[q] = rows;
-      qents[q] = ents;
-      done[q].store(1, std::memory_order_release);
-    }
-    dfs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dfs0).count();
-  });
-  auto wait_for = [&](int32_t q) {
-    while (!done[q].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-  };
+  std::unique_ptr<SeedPlan> plan_owner;
+  if (qb->plan && qb->plan->db == db && qb->plan->page == page && qb->plan->max_seed_length == opts->max_seed_length &&
+      qb->plan->hybrid_threshold == opts->hybrid_threshold) {
+    plan_owner = std::move(qb->plan);
+  } else {
+    plan_owner = start_seed_plan(ctx, qb, db, page, opts->max_seed_length, opts->hybrid_threshold);
+  }
+  SeedPlan &plan = *plan_owner;
+  std::vector<std::vector<SeedCandidate>> &per_q = plan.per_q;
+  std::vector<double> &qpairs = plan.qpairs;
+  std::vector<int64_t> &qrows = plan.qrows, &qents = plan.qents;
+  auto wait_for = [&](int32_t q) { plan.wait_for(q); };
+  std::thread &producer = plan.producer;
   auto *hs = new prb_hitset();
   hs->device = ctx->device;
   hs->on_device = ctx->keep_device_records && last_stage == 3;
@@ -1405,7 +1473,7 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     if (rc == PRB_OK) rc = drc;
     hs->drain = nullptr;
   }
-  ctx->timers["host_dfs"].ms += dfs_ms;       // wall time of the background DFS
+  ctx->timers["host_dfs"].ms += plan.dfs_ms;  // wall time of the background DFS
   ctx->timers["host_dfs"].launches++;
   ctx->timers["host_dfs_wait"].ms += wait_ms; // what the GPU pipeline actually waited for it
   ctx->timers["host_dfs_wait"].launches++;

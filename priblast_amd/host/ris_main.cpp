@@ -268,7 +268,7 @@ int txt_main(int argc, char **argv) {
 
 // encode + suffix arrays + accessibilities of the queries `idx` under context c
 Prepared prepare_batch(prb_ctx *c, const std::vector<std::string> &seqs, const std::vector<size_t> &idx, int W, int delta,
-                       int repeat_flag) {
+                       int repeat_flag, const prb_db *db, const prb_ris_opts *opts) {
   std::string cat;
   std::vector<int64_t> off(idx.size() + 1, 0);
   for (size_t k = 0; k < idx.size(); k++) {
@@ -277,6 +277,9 @@ Prepared prepare_batch(prb_ctx *c, const std::vector<std::string> &seqs, const s
   }
   Prepared p;
   if (prb_qbatch_create(c, (int32_t)idx.size(), cat.data(), off.data(), repeat_flag, &p.qb)) die(prb_last_error());
+  // the seed DFS against the first page needs no GPU: it runs on host threads beside the accessibilities (and,
+  // for a batch prepared ahead, beside the previous batch's search)
+  if (db && prb_qbatch_seed_search_begin(c, p.qb, db, 0, opts)) die(prb_last_error());
   if (prb_qbatch_accessibility(c, p.qb, W, delta)) die(prb_last_error());
   p.qlen_unmasked.resize(idx.size());
   for (size_t q = 0; q < idx.size(); q++) p.qlen_unmasked[q] = prb_qbatch_length_unmasked(p.qb, (int32_t)q);
@@ -501,17 +504,17 @@ int ris_main(int argc, char **argv) {
     size_t b = 0, bn = 0;
     bool have = next_batch(b);
     Prepared cur;
-    if (have) cur = prepare_batch(w.prep_ctx ? w.prep_ctx : w.ctx, seqs, batch_idx(b), W, delta, repeat_flag);
+    if (have) cur = prepare_batch(w.prep_ctx ? w.prep_ctx : w.ctx, seqs, batch_idx(b), W, delta, repeat_flag, w.db, &a.o);
     while (have) {
       const bool more = next_batch(bn);
       Prepared nxt;
       std::thread helper;
-      if (more && w.prep_ctx) helper = std::thread([&] { nxt = prepare_batch(w.prep_ctx, seqs, batch_idx(bn), W, delta, repeat_flag); });
+      if (more && w.prep_ctx) helper = std::thread([&] { nxt = prepare_batch(w.prep_ctx, seqs, batch_idx(bn), W, delta, repeat_flag, w.db, &a.o); });
       std::vector<prb_hitset *> pages;
       search_batch(w, a, cur, npages, pages);
       finish(b, &cur, pages);
       if (helper.joinable()) helper.join();
-      else if (more) nxt = prepare_batch(w.ctx, seqs, batch_idx(bn), W, delta, repeat_flag);
+      else if (more) nxt = prepare_batch(w.ctx, seqs, batch_idx(bn), W, delta, repeat_flag, w.db, &a.o);
       cur = std::move(nxt);
       b = bn;
       have = more;
