@@ -856,8 +856,9 @@ static int filter_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, do
 // Drops the hits whose energy is above `thr` (they cannot survive CheckRedundancy nor influence
 // it, see k_flag_not_above): recbuf <- the kept hits of in, in order, as records for the sort that
 // follows; idxbuf[i] = index in `in`.
+// `have` records already in recbuf are kept (the new ones are appended behind them).
 static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n, double thr, DevBuf &idxbuf, DevBuf &recbuf,
-                         int64_t *m) {
+                         int64_t *m, int64_t have = 0) {
   int rc;
   *m = 0;
   if (n == 0) return PRB_OK;
@@ -874,8 +875,18 @@ static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n,
   PRB_HIP(hipMemcpyAsync(&cnt, w.count.p, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
   PRB_HIP(hipStreamSynchronize(ctx->stream));
   *m = (int64_t)cnt;
-  if ((rc = recbuf.ensure(std::max<size_t>(cnt, 1) * sizeof(HitRec)))) return rc;
-  PRB_HIP(launch_gather_hits_to_recs(in, idxbuf.as<uint32_t>(), recbuf.as<HitRec>(), *m, ctx->stream));
+  const size_t need = ((size_t)have + std::max<size_t>(cnt, 1)) * sizeof(HitRec);
+  if (have > 0 && need > recbuf.cap) { // grow and keep what is there
+    DevBuf bigger;
+    if ((rc = bigger.ensure(need + need / 2))) return rc;
+    PRB_HIP(hipMemcpyAsync(bigger.p, recbuf.p, (size_t)have * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    recbuf.release();
+    recbuf = bigger;
+  } else if ((rc = recbuf.ensure(need))) {
+    return rc;
+  }
+  PRB_HIP(launch_gather_hits_to_recs(in, idxbuf.as<uint32_t>(), recbuf.as<HitRec>() + have, *m, ctx->stream));
   return PRB_OK;
 }
 
@@ -913,44 +924,6 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     return PRB_ERR_NOMEM;
   }
   const int32_t ncand = (int32_t)ncand64;
-  if ((rc = w.cands.ensure((size_t)ncand * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(nrows + 1) * 4)) ||
-      (rc = w.row_off.ensure((size_t)(nrows + 1) * 8)) || (rc = w.row_cand.ensure((size_t)(nrows + 1) * 4)) ||
-      (rc = w.seed_qacc.ensure((size_t)std::max<int64_t>(nqent, 1) * 8)))
-    return rc;
-  PRB_HIP(hipMemcpyAsync(w.cands.p, cd, (size_t)ncand * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = ctx->time_begin())) return rc;
-  // one extra zero entry so that the exclusive scan over nrows+1 values also yields the total
-  PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + nrows, 0, 4, ctx->stream));
-  PRB_HIP(launch_seed_qacc(w.cands.as<CandDev>(), ncand, nqent, qb->view, delta, w.seed_qacc.as<double>(), ctx->stream));
-  PRB_HIP(launch_seed_count(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.seed_qacc.as<double>(),
-                            w.row_count.as<int32_t>(), w.row_cand.as<int32_t>(), ctx->stream));
-  {
-    size_t tmp = 0;
-    auto in = rocprim::make_transform_iterator(w.row_count.as<int32_t>(), ToI64());
-    PRB_HIP(rocprim::exclusive_scan(nullptr, tmp, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nrows + 1,
-                                    rocprim::plus<int64_t>(), ctx->stream));
-    if ((rc = w.scanTmp.ensure(tmp))) return rc;
-    PRB_HIP(rocprim::exclusive_scan(w.scanTmp.p, tmp, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nrows + 1,
-                                    rocprim::plus<int64_t>(), ctx->stream));
-  }
-  int64_t nseed = 0;
-  PRB_HIP(hipMemcpyAsync(&nseed, w.row_off.as<int64_t>() + nrows, 8, hipMemcpyDeviceToHost, ctx->stream));
-  PRB_HIP(hipStreamSynchronize(ctx->stream));
-  hs->counts[0] += nseed;
-  if (nseed == 0) return ctx->time_end("seed", 2);
-  if (nseed > (int64_t)UINT32_MAX - 16) {
-    set_error("too many seed hits in one sub-batch: lower PRB_SEARCH_PAIRS, or, if a single query exceeds 4e9 seed hits against this page, build the database in smaller pages (db -c)");
-    return PRB_ERR_NOMEM;
-  }
-  if ((rc = w.hitsA.ensure(hits_bytes(nseed)))) return rc;
-  HitSoA A = carve_hits(w.hitsA, nseed);
-  PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), ncand, nrows, qb->view, pd, delta, w.seed_qacc.as<double>(),
-                           w.row_cand.as<int32_t>(), w.row_off.as<int64_t>(), A, ctx->stream));
-  if ((rc = ctx->time_end("seed", 2))) return rc;
-  if (last_stage == 1) return download_hits(ctx, w, A, nseed, hs->hits);
-
-  // ---- ungapped extension, sort, redundancy filter ----
-  if ((rc = ctx->time_begin())) return rc;
   int max_qlen = 0;
   for (int32_t q = 0; q < qb->nq; q++) max_qlen = std::max(max_qlen, qb->len[q]);
   SortBounds sb;
@@ -959,13 +932,91 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   sb.max_qlen = max_qlen;
   for (int32_t L : pg.seq_length) sb.max_dblen = std::max(sb.max_dblen, L);
   sb.nchars = pd.nchars;
-  PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, max_qlen, ctx->stream));
-  if ((rc = ctx->time_end("ungapped", 1))) return rc;
-  // hits above the -f threshold are dropped before the sort (they cannot survive the filter)
+  // The seeds of the sub-batch are produced, extended without gaps and thinned to the hits under the -f threshold
+  // (one seed in nine) in CHUNKS of consecutive candidates of at most `chunk_pairs` (query SA entry x database SA
+  // entry) pairs each; the survivors of all chunks, in candidate order, are what the sort and the redundancy filter
+  // then see.  So the seed pools are bounded by the pair budget whatever a single query brings - a 100 kb query
+  // against a 100 M character page has 1e10 seeds - while the filter still runs over whole queries.
+  const char *cenv = getenv("PRB_SEARCH_CHUNK_PAIRS");
+  const char *benv = getenv("PRB_SEARCH_PAIRS");
+  const double chunk_pairs = cenv ? atof(cenv) : (benv ? atof(benv) : 4.0e8);
+  CandDev *cdm = const_cast<CandDev *>(cd); // (the caller's staging buffer: each candidate is rebased once, for its chunk)
   int64_t m1 = 0;
-  if ((rc = ctx->time_begin())) return rc;
-  if ((rc = compact_below(ctx, w, A, nseed, opts.interaction_threshold, w.cidx, w.hitsB, &m1))) return rc;
-  if ((rc = ctx->time_end("filter", 2))) return rc;
+  for (int32_t c0 = 0; c0 < ncand;) {
+    int32_t c1 = c0;
+    double acc = 0;
+    while (c1 < ncand) {
+      const double pairs = (double)(cd[c1].ep_q - cd[c1].sp_q + 1) * (double)(cd[c1].ep_db - cd[c1].sp_db + 1);
+      if (c1 > c0 && acc + pairs > chunk_pairs) break;
+      acc += pairs;
+      c1++;
+    }
+    const int32_t nc = c1 - c0;
+    const int64_t row_base = cd[c0].row0, ent_base = cd[c0].qoff;
+    const int64_t crows = (c1 < ncand ? cd[c1].row0 : nrows) - row_base, cents = (c1 < ncand ? cd[c1].qoff : nqent) - ent_base;
+    for (int32_t c = c0; c < c1; c++) {
+      cdm[c].row0 -= row_base;
+      cdm[c].qoff -= ent_base;
+    }
+    if ((rc = w.cands.ensure((size_t)nc * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(crows + 1) * 4)) ||
+        (rc = w.row_off.ensure((size_t)(crows + 1) * 8)) || (rc = w.row_cand.ensure((size_t)(crows + 1) * 4)) ||
+        (rc = w.seed_qacc.ensure((size_t)std::max<int64_t>(cents, 1) * 8)))
+      return rc;
+    PRB_HIP(hipMemcpyAsync(w.cands.p, cd + c0, (size_t)nc * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx->time_begin())) return rc;
+    // one extra zero entry so that the exclusive scan over crows+1 values also yields the total
+    PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + crows, 0, 4, ctx->stream));
+    PRB_HIP(launch_seed_qacc(w.cands.as<CandDev>(), nc, cents, qb->view, delta, w.seed_qacc.as<double>(), ctx->stream));
+    PRB_HIP(launch_seed_count(w.cands.as<CandDev>(), nc, crows, qb->view, pd, delta, w.seed_qacc.as<double>(),
+                              w.row_count.as<int32_t>(), w.row_cand.as<int32_t>(), ctx->stream));
+    {
+      size_t tmp = 0;
+      auto in = rocprim::make_transform_iterator(w.row_count.as<int32_t>(), ToI64());
+      PRB_HIP(rocprim::exclusive_scan(nullptr, tmp, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)crows + 1,
+                                      rocprim::plus<int64_t>(), ctx->stream));
+      if ((rc = w.scanTmp.ensure(tmp))) return rc;
+      PRB_HIP(rocprim::exclusive_scan(w.scanTmp.p, tmp, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)crows + 1,
+                                      rocprim::plus<int64_t>(), ctx->stream));
+    }
+    int64_t nseed = 0;
+    PRB_HIP(hipMemcpyAsync(&nseed, w.row_off.as<int64_t>() + crows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    hs->counts[0] += nseed;
+    c0 = c1;
+    if (nseed == 0) {
+      if ((rc = ctx->time_end("seed", 2))) return rc;
+      continue;
+    }
+    if (nseed > (int64_t)UINT32_MAX - 16) {
+      set_error("too many seed hits in one chunk of candidates (a single candidate with more than 4e9 seed hits?): lower "
+                "PRB_SEARCH_CHUNK_PAIRS");
+      return PRB_ERR_NOMEM;
+    }
+    if ((rc = w.hitsA.ensure(hits_bytes(nseed)))) return rc;
+    HitSoA A = carve_hits(w.hitsA, nseed);
+    PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), nc, crows, qb->view, pd, delta, w.seed_qacc.as<double>(),
+                             w.row_cand.as<int32_t>(), w.row_off.as<int64_t>(), A, ctx->stream));
+    if ((rc = ctx->time_end("seed", 2))) return rc;
+    if (last_stage == 1) {
+      if ((rc = download_hits(ctx, w, A, nseed, hs->hits))) return rc;
+      continue;
+    }
+    // ---- ungapped extension; hits above the -f threshold are dropped before the sort (they cannot survive the filter) ----
+    if ((rc = ctx->time_begin())) return rc;
+    PRB_HIP(launch_ungapped(A, nseed, qb->view, pd, sc, eo, max_qlen, ctx->stream));
+    if ((rc = ctx->time_end("ungapped", 1))) return rc;
+    int64_t mc = 0;
+    if ((rc = ctx->time_begin())) return rc;
+    if ((rc = compact_below(ctx, w, A, nseed, opts.interaction_threshold, w.cidx, w.hitsB, &mc, m1))) return rc;
+    if ((rc = ctx->time_end("filter", 2))) return rc;
+    m1 += mc;
+    if (m1 > (int64_t)UINT32_MAX - 16) {
+      set_error("more than 4e9 hits under the -f threshold in one sub-batch: build the database in smaller pages (db -c)");
+      return PRB_ERR_NOMEM;
+    }
+  }
+  if (last_stage == 1) return PRB_OK;
+  // ---- sort, redundancy filter ----
   if (m1 == 0) return PRB_OK;
   if ((rc = w.hitsC.ensure(hits_bytes(m1)))) return rc;
   HitSoA B = carve_hits(w.hitsC, m1);
@@ -979,7 +1030,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = ctx->time_end("filter", 3))) return rc;
   hs->counts[1] += nung;
   if (nung == 0) return PRB_OK;
-  // compact survivors into A (A's seed content is no longer needed)
+  // compact survivors into A (A's seed content is no longer needed; the last chunk's pool may be smaller than this list)
+  if ((rc = w.hitsA.ensure(hits_bytes(nung)))) return rc;
   HitSoA U = carve_hits(w.hitsA, nung);
   PRB_HIP(launch_gather_hits(B, w.surv.as<uint32_t>(), U, nung, ctx->stream));
   if ((rc = w.first.ensure((size_t)nung))) return rc;
@@ -1461,6 +1513,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     {
       HostTimer ht(ctx, "host_search_range");
       rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, nqent, hs);
+      if (rc == PRB_ERR_NOMEM) // (the seed pools are bounded by the chunk budget; what grows with a query is the list behind -f)
+        set_error(std::string(prb_last_error()) + " - the hits of queries " + std::to_string(q0) + ".." + std::to_string(q1 - 1) +
+                  " that pass -f against this page, with the gapped extension's state, do not fit the device: build the database in "
+                  "smaller pages (db -c), which bounds them per page");
     }
     // the pinned candidates are reused by the next sub-batch: their upload must be over
     if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;

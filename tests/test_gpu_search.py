@@ -102,6 +102,29 @@ def test_sub_batching_is_transparent(ctx, golden_dir, monkeypatch):
         db.close()
 
 
+def test_candidate_chunks_are_transparent(ctx, golden_dir, monkeypatch):
+    """A query whose candidate pairs exceed the budget is cut into chunks of candidates for the seed / ungapped / -f
+    part (it used to be submitted whole, pools sized from its seed count); the sort and the filters see the
+    union.  Tiny chunks on the 3-page case: every stage identical to the unchunked run."""
+    from priblast_amd import capi
+    names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
+    db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
+    qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        for stage in (1, 2, 3):
+            monkeypatch.delenv("PRB_SEARCH_CHUNK_PAIRS", raising=False)
+            ref = [capi.search_page(ctx, qb, db, p, capi.default_opts(output_style=1), stage) for p in range(db.npages)]
+            monkeypatch.setenv("PRB_SEARCH_CHUNK_PAIRS", "300")
+            got = [capi.search_page(ctx, qb, db, p, capi.default_opts(output_style=1), stage) for p in range(db.npages)]
+            for (h1, b1, c1), (h2, b2, c2) in zip(ref, got):
+                assert c1 == c2 and np.array_equal(h1, h2) and np.array_equal(b1, b2), stage
+        assert sum(r[2][0] for r in ref) > 1000
+    finally:
+        qb.close()
+        db.close()
+
+
 def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
     """prb_db_build writes byte-identical .bas/.seq/.acc/.nam/.ind files (single and paged)."""
     from priblast_amd import capi
