@@ -21,7 +21,8 @@ the accessibilities of batch k+1 are computed under a second context on another 
 lines of batch k-1 are formatted by host threads; a step therefore contains one of each.  Everything
 submitted inside the timed region is finished inside it.  Weak scaling: every rank processes its own
 `--queries` per step; N > 1: the final hits of every rank are gathered on rank 0 over RCCL
-(prb_gather_hits) and rank 0 writes all lines.
+(prb_gather_hits, on a stream and a host thread of its own, behind the next batch's search) and rank 0
+writes all lines.
 
 One JSON line is printed by rank 0 (contract in the task description) with
   roofline     : dominant kernel (k_gapped_lds tier 0) - algorithmic bytes = 600 B per post-ungapped hit
@@ -205,6 +206,12 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL writes a version banner
+    # to stdout when a communicator is made) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -289,9 +296,27 @@ def main():
             except BaseException as e:  # noqa: BLE001 - re-raised by the consumer
                 self.err = e
 
-    def format_lines(names, qlen, pages, id0):
+    def finish_batch(k, sets, names, qlen):
+        try:
+            finish_batch_(k, sets, names, qlen)
+        except BaseException as e:  # noqa: BLE001 - re-raised by join_format
+            state["fmt_err"] = e
+
+    def finish_batch_(k, sets, names, qlen):
+        pages = [(hs.hits, hs.bp) for hs in sets]
+        if multi:
+            t3 = time.perf_counter()
+            got = comm.gather_batch(sets, qlen)
+            if rank == 0:
+                pages, nq_of, qlen = got
+                names = [n for r in range(world) for n in qnames[slice(*pdist.batch_slice(k, r, world, a.queries))]]
+            wall["final hit gather (RCCL; behind the next search)"] += time.perf_counter() - t3
+        del sets
+        if rank != 0:
+            return
         t0 = time.perf_counter()
-        lines, nbytes = capi.write_lines(db, names, qlen, pages, opts.output_style, id0, devnull)
+        lines, nbytes = capi.write_lines(db, names, qlen, pages, opts.output_style, state["id"], devnull)
+        state["id"] += lines
         sink["lines"] += lines
         sink["bytes"] += nbytes
         wall["result lines (host threads, behind the GPU work)"] += time.perf_counter() - t0
@@ -300,6 +325,8 @@ def main():
         if state["fmt"] is not None:
             state["fmt"].join()
             state["fmt"] = None
+        if state.get("fmt_err") is not None:
+            raise state["fmt_err"]
 
     def step(k):
         """one batch of a.queries queries of this rank through the whole path"""
@@ -326,21 +353,11 @@ def main():
         qb.close()
         wall["search (DFS + GPU stages + download)"] += time.perf_counter() - t2
         names = qnames[lo:hi]
-        pages = [(hs.hits, hs.bp) for hs in sets]
-        if multi:  # final hit gather over RCCL: the packed records of every rank's batch, device to device, to rank 0
-            t3 = time.perf_counter()
-            got = comm.gather_batch(sets, qlen)
-            if rank == 0:
-                pages, nq_of, qlen = got
-                names = [n for r in range(world) for n in qnames[slice(*pdist.batch_slice(k, r, world, a.queries))]]
-            wall["final hit gather (RCCL)"] += time.perf_counter() - t3
-        del sets
-        join_format()  # at most one batch of lines in flight
-        if rank == 0:
-            nlines = sum(len(h) for h, _ in pages)
-            state["fmt"] = threading.Thread(target=format_lines, args=(names, qlen, pages, state["id"]))
-            state["fmt"].start()
-            state["id"] += nlines
+        join_format()  # at most one batch of gather + lines in flight
+        # behind the next batch's search, on a host thread: the final hit gather over RCCL (N > 1: the packed records of every
+        # rank's batch, device to device, to rank 0 - every rank's thread issues its gathers in step order) and the result lines
+        state["fmt"] = threading.Thread(target=finish_batch, args=(k, sets, names, qlen))
+        state["fmt"].start()
         return total
 
     def drain():
@@ -416,7 +433,7 @@ def main():
         }
         if world == 1:
             res["cpu_baseline"] = cpu_baseline(a, ctx, a.workdir, qnames, qseqs, log)
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if state["prep"] is not None and state["prep"].qb is not None:
         state["prep"].qb.close()
     if comm is not None:

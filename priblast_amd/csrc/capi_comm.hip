@@ -104,6 +104,7 @@ struct prb_comm {
   prb_ctx *ctx = nullptr;
   void *comm = nullptr;
   int32_t nranks = 1, rank = 0;
+  hipStream_t stream = nullptr; // the gather's own stream: it may run (from another host thread) beside the next search
   DevBuf meta, meta_all, qlen, rx_hits, rx_bp, rx_qlen;
   // pinned slots: a gathered hit set lives in one until it is freed (possibly by another thread)
   struct Slot {
@@ -163,7 +164,12 @@ int prb_comm_create(prb_ctx *ctx, int32_t nranks, int32_t rank, const char id[PR
   c->rank = rank;
   UniqueId u;
   std::memcpy(u.internal, id, PRB_COMM_ID_BYTES);
+  if (hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipStreamCreateWithFlags");
+  }
   if (int e = r.CommInitRank(&c->comm, nranks, u, rank)) {
+    (void)hipStreamDestroy(c->stream);
     delete c;
     return rccl_fail(e, "ncclCommInitRank");
   }
@@ -175,8 +181,9 @@ int prb_comm_create(prb_ctx *ctx, int32_t nranks, int32_t rank, const char id[PR
 void prb_comm_destroy(prb_comm *c) {
   if (!c) return;
   (void)hipSetDevice(c->ctx->device);
-  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)rccl().CommDestroy(c->comm);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   for (DevBuf *b : {&c->meta, &c->meta_all, &c->qlen, &c->rx_hits, &c->rx_bp, &c->rx_qlen}) b->release();
   for (auto &sl : c->slots) {
     sl->hits.release();
@@ -199,7 +206,7 @@ int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32
   }
   Rccl &r = rccl();
   prb_ctx *ctx = c->ctx;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = c->stream; // (the records of `mine` are complete: prb_search_page returns after its last copy)
   PRB_HIP(hipSetDevice(ctx->device));
   const int n = c->nranks;
   int rc;
