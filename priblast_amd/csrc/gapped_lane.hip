@@ -15,25 +15,23 @@
 //     no cell pending, the step to its next anti-diagonal), so no lane waits for another lane's cells;
 //     only the changes of direction / hit happen at common iterations (every kPeriod), because their code
 //     is long and would otherwise be walked through by the whole wavefront at every iteration;
-//   * and they vote: advancing to the next anti-diagonal (A), one candidate of the current cell (E) and
-//     closing a cell (F) are three different pieces of code; an iteration of the wavefront runs the ONE that
-//     most lanes are waiting for (a uniform branch), the others wait a turn - instead of every lane walking
-//     through all three for its one (measured on the first form: 16 of 64 lanes active per instruction);
-//   * state per lane: the filled-cell list (8-byte energy + 4-byte record) in LDS, transposed ([slot][lane]:
-//     conflict-free whatever slot a lane is at) - 18 KB per wavefront, so eight of them share a CU; the two
-//     cumulative accessibility arrays in a per-wavefront block of HBM that stays in L2, read one cell ahead
-//     of their use; everything else in registers.
-// STATUS (round 2): correct (bit-identical, see below) but NOT faster than the LDS tiers yet, so the cascade
-// uses it only when PRB_GAPPED_LANE is set.  Measured on MI355X, 37.7 M hits (profiles/r02_gapped_lane.md):
-// 1,231 wave-level VALU instructions per hit in the first form (all three pieces of code in every iteration;
-// 3,074 in LDS tier 0) at 16 of 64 lanes active per instruction, but 6.2 ns per hit against tier 0's 5.1: at
-// 256 VGPRs and 38 KB of LDS per wavefront one wavefront per SIMD is resident, and its time is the sum of its
-// LDS / table / L2 latencies (time scaled 1 : 1.6 : 2.7 with 4 : 3 : 2 wavefronts per CU).  With the vote the
-// instruction count halves and the wall time doubles - fewer lanes advance per iteration while the latency per
-// iteration stays.  Pooling the cell lists per wavefront to get to 4 wavefronts per SIMD was tried and reverted
-// (the pool that fits is too small for 64 live lists: 53 % of the hits complete, 201 spilled registers): the LDS
-// that 64 directions need allows two wavefronts per SIMD, which is not enough.  Kept as the reference point for a
-// per-hit state that is smaller than 12 bytes per cell.
+//   * state per lane: the records of the filled-cell list (4 bytes per cell) in LDS, transposed ([slot][lane]:
+//     conflict-free whatever slot a lane is at) - 12 KB per wavefront; the cells' energies and the two cumulative
+//     accessibility arrays in a per-wavefront block of HBM that stays in L2 (accessibility sums read one cell ahead
+//     of their use); everything else in registers - 160 of them, i.e. three wavefronts per SIMD.
+// STATUS (round 2): correct (bit-identical, see below) but NOT faster than the LDS tiers, so the cascade uses it
+// only when PRB_GAPPED_LANE is set.  Measured on MI355X, 37.7 M hits (profiles/r02_gapped_lane.md): this form
+// (27 anti-diagonals / 48 cells per direction) completes 86 % of the hits in 186 ms and leaves tier 0 50 ms of
+// work: 236 ms against tier 0's 190 ms on everything.  It needs ~1,300 wave-level VALU instructions per hit where
+// tier 0 needs 3,074, but at ~25 % of the lanes active (advance / candidate / close are three different pieces of
+// code and every iteration walks through all three) and 60 % VALU busy.  Forms tried on the way: state in LDS and
+// 256 registers (one wavefront per SIMD: 233 ms for 20 / 24 capacities - latency bound, time inversely
+// proportional to the resident wavefronts); a vote for ONE piece per iteration (half the instructions, but every
+// lane waits for its piece to come up: 261 ms); cell lists pooled per wavefront in 4-cell chunks (the pool that
+// fits is too small for 64 live lists: 53 % complete).  What took it from one to three wavefronts per SIMD was a
+// dynamically indexed register array in the window set-up (the extension's direction differs per lane): memory
+// order + v_bfrev instead, 256 -> 160 registers.  To beat tier 0 clearly it would need half its instructions
+// again (cheaper changes of direction: ~300 of the 1,300; the anti-diagonal masks kept incrementally).
 // A direction that outgrows the capacities (kD anti-diagonals, kR cells) is left to the LDS tiers of
 // gapped_lds.hip: the hit is flagged, and if its first direction was completed here that result is
 // handed over (kResumeMark) exactly as between those tiers.  Results are bit-identical to them
@@ -50,14 +48,14 @@ namespace {
 
 constexpr int kPeriod = 16; // iterations between two points where lanes change direction / hit
 
-template <int D, int R> struct LaneLds { // the cell list; per wavefront
-  double hyb[R][64];
+template <int D, int R> struct LaneLds { // the records of the cell lists; per wavefront
   uint32_t info[R][64];
 };
 // the cumulative accessibility arrays of a wavefront's 64 directions, in HBM / L2 (written once per direction,
 // read twice per filled cell, one cell ahead of their use): eq[slot][lane], ed[slot][lane]
-template <int D> struct LaneAcc {
+template <int D, int R = kLaneCapR> struct LaneAcc {
   double eq[D][64], ed[D][64];
+  double hyb[R][64]; // the cells' energies: written once, read once per later cell that has it as a candidate
 };
 
 // the bases of one strand along the extension: bit t of lo / hi / valid describes position t
@@ -88,14 +86,18 @@ __device__ __forceinline__ Planes load_planes(const uint8_t *s, int64_t n, int64
 #pragma unroll
   for (int k = 0; k < 8; k++) x[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], (uint32_t)sh); // bytes of positions first + 4k ..
 #pragma unroll
-  for (int t = 0; t < 32; t++) {
-    const int u = dir > 0 ? t : 31 - t; // position first + u is step t of the extension
+  for (int u = 0; u < 32; u++) { // in memory order (static register indices); a leftward extension is the mirror image
     const uint32_t c = (x[u >> 2] >> ((u & 3) * 8)) & 0xFF;
     const int64_t pos = first + u;
     const uint32_t ok = (pos >= 0 && pos < n && c >= 2) ? 1u : 0u;
-    p.lo |= (c & 1) << t;
-    p.hi |= ((c >> 1) & 1) << t;
-    p.valid |= ok << t;
+    p.lo |= (c & 1) << u;
+    p.hi |= ((c >> 1) & 1) << u;
+    p.valid |= ok << u;
+  }
+  if (dir < 0) { // position first + u is step 31 - u of the extension
+    p.lo = __builtin_bitreverse32(p.lo);
+    p.hi = __builtin_bitreverse32(p.hi);
+    p.valid = __builtin_bitreverse32(p.valid);
   }
   p.lo &= p.valid;
   p.hi &= p.valid;
@@ -178,11 +180,11 @@ __device__ __forceinline__ void lane_dir_init(const GapArgs &a, LaneLds<D, R> &S
   st.acc_q = 0;
   st.acc_d = 0;
   st.staged = 0;
-#pragma unroll 4
-  for (int len = 1; len <= (D < 16 ? D : 16); len++) lane_stage<D>(a, A, lane, st, len); // (the loads of four lengths in flight together)
+#pragma unroll 2
+  for (int len = 1; len <= (D < 16 ? D : 16); len++) lane_stage<D>(a, A, lane, st, len); // (registers: the loads of two lengths in flight together)
   int type0 = bp_type(sc, q0, d0);
   if (st.flag == 0) type0 = rtype_of(type0);
-  S.hyb[0][lane] = st.min_e;
+  A.hyb[0][lane] = st.min_e;
   S.info[0][lane] = Rec32::pack(0, 0, 0, type0, q1, d1);
   st.t0 = type0 != 0 ? 1u : 0u; // cell (0, 0) lies on anti-diagonal 0
   st.w0m = wobble(type0) ? 1u : 0u;
@@ -201,17 +203,20 @@ __device__ __forceinline__ void diag_masks(const LaneState &st, int len, uint32_
   pairs = both & ldiff & ((st.q.hi ^ dh) | gu);
 }
 
+constexpr int kLaneWaves = 4; // wavefronts per workgroup (independent of each other)
 template <int D, int R>
-__global__ __launch_bounds__(64) void k_gapped_lane(GapArgs a) {
-  __shared__ LaneLds<D, R> S;
-  const int lane = threadIdx.x;
-  LaneAcc<D> &A = reinterpret_cast<LaneAcc<D> *>(a.lane_scratch)[blockIdx.x];
+__global__ __launch_bounds__(64 * kLaneWaves, 3) void k_gapped_lane(GapArgs a) {
+  __shared__ LaneLds<D, R> lds[kLaneWaves];
+  const int lane = threadIdx.x & 63;
+  LaneLds<D, R> &S = lds[threadIdx.x >> 6];
+  const int64_t wave_id = (int64_t)blockIdx.x * kLaneWaves + (threadIdx.x >> 6);
+  LaneAcc<D> &A = reinterpret_cast<LaneAcc<D> *>(a.lane_scratch)[wave_id];
   const SearchConst &sc = a.sc;
   const int drop = a.o.drop_w_gap, min_helix = a.o.min_helix;
   enum { kLoad, kInit, kRun, kFinished, kDone };
   LaneState st;
-  st.w = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t nlanes = (int64_t)gridDim.x * 64;
+  st.w = wave_id * 64 + lane;
+  const int64_t nlanes = (int64_t)gridDim.x * kLaneWaves * 64;
   int phase = st.w < a.n ? kLoad : kDone;
   int tick = 0;
   while (__ballot(phase != kDone) != 0) {
@@ -325,14 +330,10 @@ __global__ __launch_bounds__(64) void k_gapped_lane(GapArgs a) {
     }
     tick = tick + 1 == kPeriod ? 0 : tick + 1;
 
-    // ---- the vote: which piece of code runs in this iteration ----
-    const bool run = phase == kRun;
-    const bool want_a = run && st.pend == 0, want_e = run && st.pend != 0 && st.k < st.dstart,
-               want_f = run && st.pend != 0 && st.k >= st.dstart;
-    const int n_a = __popcll(__ballot(want_a)), n_e = __popcll(__ballot(want_e)), n_f = __popcll(__ballot(want_f));
-    const int pick = (n_e >= n_a && n_e >= n_f) ? 1 : (n_a >= n_f ? 0 : 2);
-
-    if (pick == 0) {
+    // Every iteration walks through all three pieces (a vote for ONE piece per iteration was tried: fewer instructions,
+    // but every lane then waits for its piece to come up - slower).
+    const bool want_a = phase == kRun && st.pend == 0;
+    {
       // ---- A: on to the next anti-diagonal (gapped_extension.cpp:129-219, 292-297) ----
       if (want_a) {
         bool stop = false;
@@ -398,13 +399,14 @@ __global__ __launch_bounds__(64) void k_gapped_lane(GapArgs a) {
           }
         }
       }
-    } else if (pick == 1) {
+    }
+    {
       // ---- E: one candidate of the first pending cell (:220-254) ----
-      if (want_e) {
+      if (phase == kRun && st.pend != 0 && st.k < st.dstart) {
         const int ci = __builtin_ctz(st.pend), cj = st.length - ci;
         const bool f0 = st.flag == 0;
         const uint32_t v = S.info[st.k][lane];
-        const double hk = S.hyb[st.k][lane];
+        const double hk = A.hyb[st.k][lane];
         const int ri = Rec32::i(v), rj = Rec32::j(v);
         if (ri < ci && rj < cj) {
           // the bases of the new pair and next to it on the loop side (bit 31 - t of the database planes = position t)
@@ -428,9 +430,10 @@ __global__ __launch_bounds__(64) void k_gapped_lane(GapArgs a) {
         }
         st.k++;
       }
-    } else {
+    }
+    {
       // ---- F: the cell is done: its record, the running minimum (:256-278) ----
-      if (want_f) {
+      if (phase == kRun && st.pend != 0 && st.k >= st.dstart) {
         if (st.nrec >= R) {
           st.overflow = true;
           phase = kFinished;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) void k_gapped_lane(GapArgs a) {
           int bk = st.bkp >> 3, ptype = st.bkp & 7;
           if (st.lo >= st.dstart) bk = 0;                        // empty window: the reference reads stem_candidate[0] of an empty list
           if (ptype == 0) ptype = Rec32::type(S.info[bk][lane]); // no candidate qualified: the type of that default entry
-          S.hyb[st.nrec][lane] = st.bte;
+          A.hyb[st.nrec][lane] = st.bte;
           S.info[st.nrec][lane] = Rec32::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
           st.t0 |= (ptype != 0 ? 1u : 0u) << ci;
           st.w0m |= (wobble(ptype) ? 1u : 0u) << ci;
@@ -488,7 +491,7 @@ bool gapped_lane_supported(const SearchConst &sc, const ExtOpts &o) {
          o.drop_w_gap + 1 <= 18;
 }
 
-size_t gapped_lane_scratch_bytes() { return (size_t)256 * 32 * sizeof(LaneAcc<kLaneCapD>); } // a block per resident wavefront
+size_t gapped_lane_scratch_bytes() { return (size_t)256 * 16 * sizeof(LaneAcc<kLaneCapD>); } // a block per resident wavefront
 
 hipError_t launch_gapped_lane(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                               const SearchConst &sc, ExtOpts o, int tier_id, uint8_t *overflow, uint8_t *tier_out, int32_t *bp_count,
@@ -499,12 +502,13 @@ hipError_t launch_gapped_lane(const HitSoA &in, HitSoA out, int64_t n, const uin
   a.lane_scratch = scratch;
   const int64_t want = (n + 63) / 64;
   if (hipError_t e = hipMemsetAsync(next_work, 0, sizeof(unsigned long long), s); e != hipSuccess) return e;
-  auto go = [&](auto kern, size_t lds) {
-    const int waves_per_cu = std::min<int>(32, (int)((160 * 1024) / lds));
-    const dim3 grid((unsigned)std::min<int64_t>(want, 256 * waves_per_cu)), blk(64);
-    hipLaunchKernelGGL(kern, grid, blk, 0, s, a);
-  };
-  go(k_gapped_lane<kLaneCapD, kLaneCapR>, sizeof(LaneLds<kLaneCapD, kLaneCapR>));
+  {
+    constexpr size_t lds = sizeof(LaneLds<kLaneCapD, kLaneCapR>) * kLaneWaves;
+    const int blocks_per_cu = std::min<int>(12 / kLaneWaves, (int)((160 * 1024) / lds)); // three wavefronts per SIMD (160 VGPRs)
+    const int64_t want_blocks = (want + kLaneWaves - 1) / kLaneWaves;
+    const dim3 grid((unsigned)std::min<int64_t>(want_blocks, 256 * blocks_per_cu)), blk(64 * kLaneWaves);
+    hipLaunchKernelGGL((k_gapped_lane<kLaneCapD, kLaneCapR>), grid, blk, 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -188,7 +188,7 @@ constexpr int kLdsTiers = 4, kWaveTier = 4;
 // launch_gapped_lane (gapped_lane.hip): the first kernel of the cascade, a lane per hit, kLaneCapD anti-diagonals and
 // kLaneCapR filled cells per direction; hits that outgrow it are flagged in overflow[] (with direction 0
 // handed over when it was completed) and go on to the LDS tiers.  Completed hits are reported as `tier_id`.
-constexpr int kLaneCapD = 27, kLaneCapR = 24;
+constexpr int kLaneCapD = 27, kLaneCapR = 48;
 size_t gapped_lane_scratch_bytes(); // HBM scratch of a launch (accessibility sums of the resident wavefronts)
 bool gapped_lane_supported(const SearchConst &sc, const ExtOpts &o);
 hipError_t launch_gapped_lane(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
