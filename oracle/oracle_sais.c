@@ -12,8 +12,10 @@
 
 #include "oracle.h"
 
-static const int32_t *g_rank;
-static int g_k, g_n;
+/* qsort has no context argument: per thread, because orc_ris builds the suffix arrays of several queries at once
+ * (shared globals here gave a wrong suffix array once in a few runs - a test that failed now and then) */
+static _Thread_local const int32_t *g_rank;
+static _Thread_local int g_k, g_n;
 
 static int cmp_pair(const void *pa, const void *pb) {
   int32_t a = *(const int32_t *)pa, b = *(const int32_t *)pb;

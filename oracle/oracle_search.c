@@ -11,8 +11,8 @@
  *   SaveMyResults / MergeOutput formatting                       rna_interaction_search.cpp:322-369,445-476
  *
  * Known deliberate deviations (documented in DESIGN.md): the hit sort is made a total
- * order (ties of the reference's 4-key comparator are broken by energy, then input
- * order) - the reference's std::sort leaves ties unspecified; output lines are written
+ * order (ties of the reference's 4-key comparator are broken by energy, its two parts, then
+ * input order) - the reference's std::sort leaves ties unspecified; output lines are written
  * in (query, page, hit) order with a running Id (the reference's order is
  * thread-finish order).  Tests compare sorted bodies with the Id column stripped.
  */
@@ -298,7 +298,8 @@ static void ungapped_one(orc_hit *h, const orc_page *pg, const uint8_t *qs, cons
 
 typedef struct { orc_hit h; size_t ord; } sort_rec;
 
-/* compare, rna_interaction_search.cpp:45-55 + total-order tie-break (energy, input order) */
+/* compare, rna_interaction_search.cpp:45-55 + total-order tie-break (energy, its hybridization part, its accessibility
+ * part, input order): hits that are still tied are identical in every field, so the order of the input is immaterial */
 static int hit_cmp(const void *pa, const void *pb) {
   const sort_rec *a = pa, *b = pb;
   if (a->h.db_sp != b->h.db_sp) return a->h.db_sp < b->h.db_sp ? -1 : 1;
@@ -306,6 +307,8 @@ static int hit_cmp(const void *pa, const void *pb) {
   if (US(a->h.db_len) != US(b->h.db_len)) return US(a->h.db_len) > US(b->h.db_len) ? -1 : 1;
   if (US(a->h.q_len) != US(b->h.q_len)) return US(a->h.q_len) > US(b->h.q_len) ? -1 : 1;
   if (a->h.e_tot != b->h.e_tot) return a->h.e_tot < b->h.e_tot ? -1 : 1;
+  if (a->h.e_hyb != b->h.e_hyb) return a->h.e_hyb < b->h.e_hyb ? -1 : 1;
+  if (a->h.e_acc != b->h.e_acc) return a->h.e_acc < b->h.e_acc ? -1 : 1;
   return a->ord < b->ord ? -1 : (a->ord > b->ord ? 1 : 0);
 }
 

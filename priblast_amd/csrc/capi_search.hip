@@ -38,7 +38,7 @@ struct SearchConstMem {
 };
 
 struct PageMem {
-  DevBuf seqs, sa, sa_seq, start_pos, seq_length, acc, cond;
+  DevBuf seqs, sa, sa_seq, blk_seq, start_pos, seq_length, acc, cond;
   PageDev view{};
 };
 
@@ -46,12 +46,13 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, laneScratch;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, laneScratch, pair0;
+  std::vector<int64_t> pair0_host;
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &laneScratch})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &laneScratch, &pair0})
       b->release();
     pinned.release();
     cand_pinned.release();
@@ -351,9 +352,11 @@ static int upload_page(const DbPage &pg, PageMem &m, hipStream_t stream) {
   if ((rc = up(m.acc, pg.acc.data(), pg.acc.size() * 4))) return rc;
   if ((rc = up(m.cond, pg.cond.data(), pg.cond.size() * 4))) return rc;
   if ((rc = m.sa_seq.ensure(std::max<size_t>(pg.sa.size() * 4, 16)))) return rc;
+  if ((rc = m.blk_seq.ensure((size_t)blk_seq_entries((int64_t)pg.seqs.size()) * 4))) return rc;
   m.view.seqs = m.seqs.as<uint8_t>();
   m.view.sa = m.sa.as<int32_t>();
   m.view.sa_seq = m.sa_seq.as<int32_t>();
+  m.view.blk_seq = m.blk_seq.as<int32_t>();
   m.view.start_pos = m.start_pos.as<int32_t>();
   m.view.seq_length = m.seq_length.as<int32_t>();
   m.view.acc = m.acc.as<float>();
@@ -361,6 +364,7 @@ static int upload_page(const DbPage &pg, PageMem &m, hipStream_t stream) {
   m.view.nchars = (int32_t)pg.seqs.size();
   m.view.nseq = pg.nseq;
   PRB_HIP(launch_sa_seq(m.view, m.sa_seq.as<int32_t>(), stream));
+  PRB_HIP(launch_blk_seq(m.view, m.blk_seq.as<int32_t>(), stream));
   return PRB_OK;
 }
 
@@ -483,7 +487,7 @@ void prb_db_close(prb_db *db) {
       if (!pg.cond.empty()) (void)hipHostUnregister(pg.cond.data());
     }
   for (auto &m : db->mem)
-    for (DevBuf *b : {&m.seqs, &m.sa, &m.sa_seq, &m.start_pos, &m.seq_length, &m.acc, &m.cond}) b->release();
+    for (DevBuf *b : {&m.seqs, &m.sa, &m.sa_seq, &m.blk_seq, &m.start_pos, &m.seq_length, &m.acc, &m.cond}) b->release();
   delete db;
 }
 
@@ -713,7 +717,8 @@ int prb_qbatch_seed_search_begin(prb_ctx *ctx, prb_qbatch *qb, const prb_db *db,
 namespace prb {
 
 // Sorts `in` (n hits) into `out` by the reference's comparator made total:
-// (query, db_sp asc, q_sp asc, db_len desc, q_len desc, energy asc, input order);
+// (query, db_sp asc, q_sp asc, db_len desc, q_len desc, energy asc, hybridization part asc, accessibility part asc,
+// input order);
 // LSD: one stable radix sort per key, least significant first.  perm_out[i] = index in `in`.
 // Field bounds of the hits of one sub-batch, for the one-key sort
 struct SortBounds {
@@ -751,8 +756,8 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitRec *recs, HitSoA out, 
                                         w.idxB.as<uint32_t>(), N, 0, (unsigned)total, ctx->stream));
       PRB_HIP(launch_gather_u64(w.kE.as<uint64_t>(), w.idxB.as<uint32_t>(), w.kTmp.as<uint64_t>(), n, ctx->stream));
       PRB_HIP(hipMemsetAsync(w.pending.p, 0, 4, ctx->stream));
-      PRB_HIP(launch_fix_ties(w.kTmp2.as<uint64_t>(), w.kTmp.as<uint64_t>(), w.idxB.as<uint32_t>(), n, w.pending.as<int32_t>(),
-                              ctx->stream));
+      PRB_HIP(launch_fix_ties(w.kTmp2.as<uint64_t>(), w.kTmp.as<uint64_t>(), w.idxB.as<uint32_t>(), n, recs,
+                              w.pending.as<int32_t>(), ctx->stream));
       int32_t too_long = 0;
       PRB_HIP(hipMemcpyAsync(&too_long, w.pending.p, 4, hipMemcpyDeviceToHost, ctx->stream));
       PRB_HIP(hipStreamSynchronize(ctx->stream));
@@ -790,7 +795,14 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitRec *recs, HitSoA out, 
     std::swap(ia, ib);
     return PRB_OK;
   };
-  if ((rc = sort64(w.kE.as<uint64_t>(), 64))) return rc; // keys already in input order
+  // least significant first: accessibility part, hybridization part, energy
+  PRB_HIP(launch_order_keys(in.e_acc, n, w.kTmp.as<uint64_t>(), ctx->stream));
+  if ((rc = sort64(w.kTmp.as<uint64_t>(), 64))) return rc; // keys in input order
+  PRB_HIP(launch_order_keys(in.e_hyb, n, w.kTmp2.as<uint64_t>(), ctx->stream));
+  PRB_HIP(launch_gather_u64(w.kTmp2.as<uint64_t>(), ia, w.kTmp.as<uint64_t>(), n, ctx->stream));
+  if ((rc = sort64(w.kTmp.as<uint64_t>(), 64))) return rc;
+  PRB_HIP(launch_gather_u64(w.kE.as<uint64_t>(), ia, w.kTmp.as<uint64_t>(), n, ctx->stream));
+  if ((rc = sort64(w.kTmp.as<uint64_t>(), 64))) return rc;
   PRB_HIP(launch_gather_u32(w.kL.as<uint32_t>(), ia, w.kTmp.as<uint32_t>(), n, ctx->stream));
   if ((rc = sort32(w.kTmp.as<uint32_t>(), 32))) return rc;
   PRB_HIP(launch_gather_u32(w.kQ.as<uint32_t>(), ia, w.kTmp.as<uint32_t>(), n, ctx->stream));
@@ -857,6 +869,22 @@ static int filter_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, do
 // it, see k_flag_not_above): recbuf <- the kept hits of in, in order, as records for the sort that
 // follows; idxbuf[i] = index in `in`.
 // `have` records already in recbuf are kept (the new ones are appended behind them).
+// Room for `more` records behind the `have` records that `recbuf` holds (which are kept).
+static int reserve_recs(prb_ctx *ctx, DevBuf &recbuf, int64_t have, int64_t more) {
+  int rc;
+  const size_t need = ((size_t)have + (size_t)more) * sizeof(HitRec);
+  if (have > 0 && need > recbuf.cap) { // grow and keep what is there
+    DevBuf bigger;
+    if ((rc = bigger.ensure(need + need / 2))) return rc;
+    PRB_HIP(hipMemcpyAsync(bigger.p, recbuf.p, (size_t)have * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    recbuf.release();
+    recbuf = bigger;
+    return PRB_OK;
+  }
+  return recbuf.ensure(need);
+}
+
 static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n, double thr, DevBuf &idxbuf, DevBuf &recbuf,
                          int64_t *m, int64_t have = 0) {
   int rc;
@@ -875,17 +903,7 @@ static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n,
   PRB_HIP(hipMemcpyAsync(&cnt, w.count.p, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
   PRB_HIP(hipStreamSynchronize(ctx->stream));
   *m = (int64_t)cnt;
-  const size_t need = ((size_t)have + std::max<size_t>(cnt, 1)) * sizeof(HitRec);
-  if (have > 0 && need > recbuf.cap) { // grow and keep what is there
-    DevBuf bigger;
-    if ((rc = bigger.ensure(need + need / 2))) return rc;
-    PRB_HIP(hipMemcpyAsync(bigger.p, recbuf.p, (size_t)have * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
-    PRB_HIP(hipStreamSynchronize(ctx->stream));
-    recbuf.release();
-    recbuf = bigger;
-  } else if ((rc = recbuf.ensure(need))) {
-    return rc;
-  }
+  if ((rc = reserve_recs(ctx, recbuf, have, (int64_t)std::max<size_t>(cnt, 1)))) return rc;
   PRB_HIP(launch_gather_hits_to_recs(in, idxbuf.as<uint32_t>(), recbuf.as<HitRec>() + have, *m, ctx->stream));
   return PRB_OK;
 }
@@ -940,6 +958,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   const char *cenv = getenv("PRB_SEARCH_CHUNK_PAIRS");
   const char *benv = getenv("PRB_SEARCH_PAIRS");
   const double chunk_pairs = cenv ? atof(cenv) : (benv ? atof(benv) : 4.0e8);
+  // rows in (query, database position >> row_shift) order, see k_row_key; PRB_SEED_ROW_SHIFT = -1 keeps suffix-array order
+  const char *rsenv = getenv("PRB_SEED_ROW_SHIFT");
+  const int row_shift = rsenv ? std::min(atoi(rsenv), 30) : 7;
+  const char *fenv = getenv("PRB_SEED_FUSED"); // 0: seeds written as a list, extended and thinned in separate passes
+  const bool fused = !(fenv && atoi(fenv) == 0);
   CandDev *cdm = const_cast<CandDev *>(cd); // (the caller's staging buffer: each candidate is rebased once, for its chunk)
   int64_t m1 = 0;
   for (int32_t c0 = 0; c0 < ncand;) {
@@ -947,7 +970,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     double acc = 0;
     while (c1 < ncand) {
       const double pairs = (double)(cd[c1].ep_q - cd[c1].sp_q + 1) * (double)(cd[c1].ep_db - cd[c1].sp_db + 1);
-      if (c1 > c0 && acc + pairs > chunk_pairs) break;
+      if (c1 > c0 && (acc + pairs > chunk_pairs || c1 - c0 >= kMaxFusedCands)) break;
       acc += pairs;
       c1++;
     }
@@ -967,8 +990,116 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     // one extra zero entry so that the exclusive scan over crows+1 values also yields the total
     PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + crows, 0, 4, ctx->stream));
     PRB_HIP(launch_seed_qacc(w.cands.as<CandDev>(), nc, cents, qb->view, delta, w.seed_qacc.as<double>(), ctx->stream));
+    // ---- seeds -> hits under the -f threshold in one pass over the sorted pairs (search_kernels.hip) ----
+    bool fuse = fused && last_stage != 1 && row_shift >= 0 && acc < 4.0e9;
+    if (fuse) {
+      w.pair0_host.resize((size_t)nc + 1);
+      int64_t np = 0;
+      for (int32_t c = 0; c < nc && fuse; c++) {
+        const int64_t qw = cd[c0 + c].ep_q - cd[c0 + c].sp_q + 1;
+        if (qw > kMaxFusedEntries) fuse = false;
+        w.pair0_host[(size_t)c] = np;
+        np += qw * (int64_t)(cd[c0 + c].ep_db - cd[c0 + c].sp_db + 1);
+      }
+      w.pair0_host[(size_t)nc] = np;
+    }
+    if (fuse) {
+      const int64_t np = w.pair0_host[(size_t)nc];
+      const size_t NP = (size_t)np;
+      const int qmin = cd[c0].query;
+      const int dbits = bits_for(std::max<int64_t>(1, ((int64_t)pd.nchars - 1) >> row_shift));
+      const int kbits = dbits + bits_for(std::max<int64_t>(1, (int64_t)cd[c1 - 1].query - qmin));
+      const bool wide = kbits > 32;
+      if ((rc = w.pair0.ensure(((size_t)nc + 1) * 8)) || (rc = w.kP.ensure(NP * 8)) || (rc = w.kTmp2.ensure(NP * 8)) ||
+          (rc = w.kE.ensure(NP * 8)) || (rc = w.kTmp.ensure(NP * 8)) || (rc = w.count.ensure(16)))
+        return rc;
+      PRB_HIP(hipMemcpyAsync(w.pair0.p, w.pair0_host.data(), ((size_t)nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+      PRB_HIP(launch_pair_keys(w.cands.as<CandDev>(), w.pair0.as<int64_t>(), nc, np, pd, qmin, row_shift, dbits, wide, w.kP.p,
+                               w.kE.as<uint64_t>(), ctx->stream));
+      size_t tmp = 0;
+      if (wide) {
+        PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.kE.as<uint64_t>(),
+                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
+        if ((rc = w.sortTmp.ensure(tmp))) return rc;
+        PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.kE.as<uint64_t>(),
+                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
+      } else {
+        PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint32_t>(), w.kTmp2.as<uint32_t>(), w.kE.as<uint64_t>(),
+                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
+        if ((rc = w.sortTmp.ensure(tmp))) return rc;
+        PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint32_t>(), w.kTmp2.as<uint32_t>(), w.kE.as<uint64_t>(),
+                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
+      }
+      if ((rc = ctx->time_end("seed", 2))) return rc;
+      if ((rc = ctx->time_begin())) return rc;
+      const int64_t nsl = fused_slices(np);
+      if ((rc = w.hitsA.ensure((size_t)nsl * kFusePairs * kSliceRecBytes)) || (rc = w.row_count.ensure((size_t)(nsl + 1) * 4)) ||
+          (rc = w.row_off.ensure((size_t)(nsl + 1) * 8)))
+        return rc;
+      PRB_HIP(hipMemsetAsync(w.count.p, 0, 16, ctx->stream));
+      PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + nsl, 0, 4, ctx->stream));
+      PRB_HIP(launch_seed_extend(w.cands.as<CandDev>(), w.kTmp.as<uint64_t>(), np, qb->view, pd, sc, eo, w.seed_qacc.as<double>(),
+                                 opts.interaction_threshold, max_qlen, w.hitsA.p, w.row_count.as<int32_t>(), w.count.as<uint64_t>(),
+                                 ctx->stream));
+      {
+        size_t tmp2 = 0;
+        auto in = rocprim::make_transform_iterator(w.row_count.as<int32_t>(), ToI64());
+        PRB_HIP(rocprim::exclusive_scan(nullptr, tmp2, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nsl + 1, rocprim::plus<int64_t>(),
+                                        ctx->stream));
+        if ((rc = w.scanTmp.ensure(tmp2))) return rc;
+        PRB_HIP(rocprim::exclusive_scan(w.scanTmp.p, tmp2, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nsl + 1,
+                                        rocprim::plus<int64_t>(), ctx->stream));
+      }
+      uint64_t cnt[2] = {0, 0};
+      PRB_HIP(hipMemcpyAsync(&cnt[0], w.count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipMemcpyAsync(&cnt[1], w.row_off.as<int64_t>() + nsl, 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipStreamSynchronize(ctx->stream));
+      if (cnt[1] > 0) {
+        if ((rc = reserve_recs(ctx, w.hitsB, m1, (int64_t)cnt[1]))) return rc;
+        PRB_HIP(launch_collect_slices(w.hitsA.p, w.row_count.as<int32_t>(), w.row_off.as<int64_t>(), nsl, w.hitsB.as<HitRec>() + m1,
+                                      ctx->stream));
+      }
+      if ((rc = ctx->time_end("ungapped", 1))) return rc;
+      hs->counts[0] += (int64_t)cnt[0];
+      m1 += (int64_t)cnt[1];
+      c0 = c1;
+      if (m1 > (int64_t)UINT32_MAX - 16) {
+        set_error("more than 4e9 hits under the -f threshold in one sub-batch: build the database in smaller pages (db -c)");
+        return PRB_ERR_NOMEM;
+      }
+      continue;
+    }
+    // the rows in the order of (query, database position) - not for the seed-stage output, which keeps the reference's
+    // emission order (candidate, database SA entry, query SA entry) - see k_row_key
+    const uint32_t *row_perm = nullptr;
+    if (last_stage != 1 && crows > 1 && crows < (int64_t)UINT32_MAX && row_shift >= 0) {
+      const size_t NR = (size_t)crows;
+      const int qmin = cd[c0].query;
+      const int dbits = bits_for(std::max<int64_t>(1, ((int64_t)pd.nchars - 1) >> row_shift));
+      const int kbits = dbits + bits_for(std::max<int64_t>(1, (int64_t)cd[c1 - 1].query - qmin));
+      const bool wide = kbits > 32;
+      if ((rc = w.kP.ensure(NR * 8)) || (rc = w.kTmp2.ensure(NR * 8)) || (rc = w.idxA.ensure(NR * 4)) || (rc = w.idxB.ensure(NR * 4)))
+        return rc;
+      PRB_HIP(launch_row_keys(w.cands.as<CandDev>(), nc, crows, pd, qmin, row_shift, dbits, wide, w.row_cand.as<int32_t>(), w.kP.p,
+                              w.idxA.as<uint32_t>(), ctx->stream));
+      size_t tmp = 0;
+      if (wide) {
+        PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.idxA.as<uint32_t>(),
+                                          w.idxB.as<uint32_t>(), NR, 0, (unsigned)kbits, ctx->stream));
+        if ((rc = w.sortTmp.ensure(tmp))) return rc;
+        PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.idxA.as<uint32_t>(),
+                                          w.idxB.as<uint32_t>(), NR, 0, (unsigned)kbits, ctx->stream));
+      } else {
+        PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint32_t>(), w.kTmp2.as<uint32_t>(), w.idxA.as<uint32_t>(),
+                                          w.idxB.as<uint32_t>(), NR, 0, (unsigned)kbits, ctx->stream));
+        if ((rc = w.sortTmp.ensure(tmp))) return rc;
+        PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint32_t>(), w.kTmp2.as<uint32_t>(), w.idxA.as<uint32_t>(),
+                                          w.idxB.as<uint32_t>(), NR, 0, (unsigned)kbits, ctx->stream));
+      }
+      row_perm = w.idxB.as<uint32_t>();
+    }
     PRB_HIP(launch_seed_count(w.cands.as<CandDev>(), nc, crows, qb->view, pd, delta, w.seed_qacc.as<double>(),
-                              w.row_count.as<int32_t>(), w.row_cand.as<int32_t>(), ctx->stream));
+                              w.row_count.as<int32_t>(), w.row_cand.as<int32_t>(), row_perm, ctx->stream));
     {
       size_t tmp = 0;
       auto in = rocprim::make_transform_iterator(w.row_count.as<int32_t>(), ToI64());
@@ -982,6 +1113,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     PRB_HIP(hipMemcpyAsync(&nseed, w.row_off.as<int64_t>() + crows, 8, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
     hs->counts[0] += nseed;
+    if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[rows] cands %d rows %lld qents %lld pairs %.0f seeds %lld\n", nc, (long long)crows, (long long)cents, acc, (long long)nseed);
     c0 = c1;
     if (nseed == 0) {
       if ((rc = ctx->time_end("seed", 2))) return rc;
@@ -995,7 +1127,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     if ((rc = w.hitsA.ensure(hits_bytes(nseed)))) return rc;
     HitSoA A = carve_hits(w.hitsA, nseed);
     PRB_HIP(launch_seed_emit(w.cands.as<CandDev>(), nc, crows, qb->view, pd, delta, w.seed_qacc.as<double>(),
-                             w.row_cand.as<int32_t>(), w.row_off.as<int64_t>(), A, ctx->stream));
+                             w.row_cand.as<int32_t>(), w.row_off.as<int64_t>(), A, row_perm, ctx->stream));
     if ((rc = ctx->time_end("seed", 2))) return rc;
     if (last_stage == 1) {
       if ((rc = download_hits(ctx, w, A, nseed, hs->hits))) return rc;

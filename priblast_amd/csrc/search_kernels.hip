@@ -75,17 +75,23 @@ __global__ __launch_bounds__(kBlock) void k_seed_qacc(const CandDev *__restrict_
 // One row = one (candidate, db SA entry); the query interval is walked inside the row.  The
 // count pass finds the row's candidate - a workgroup's 256 rows span at most 256 candidates,
 // whose first rows are put in LDS - and leaves it for the emit pass.
+// With `row_perm` the threads take the rows in that order (rows sorted by query and database position, see
+// k_row_key): thread t works on row row_perm[t], whose candidate k_row_key has left in row_cand; counts and offsets
+// are indexed by t.
 template <bool kEmit>
 __global__ __launch_bounds__(kBlock) void k_seed(const CandDev *__restrict__ cands, int ncand, int64_t nrows, QBatchDev qb,
                                                  PageDev pg, int delta, const double *__restrict__ qacc,
                                                  int32_t *__restrict__ row_count, int32_t *__restrict__ row_cand,
-                                                 const int64_t *__restrict__ row_off, HitSoA hits) {
+                                                 const int64_t *__restrict__ row_off, HitSoA hits,
+                                                 const uint32_t *__restrict__ row_perm) {
   __shared__ int64_t s_row0[kBlock + 1];
   __shared__ int s_c0;
-  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x; // index of the row's count / offset
+  int64_t row = slot;
   int ci;
-  if (kEmit) {
-    if (row >= nrows) return;
+  if (kEmit || row_perm) {
+    if (slot >= nrows) return;
+    if (row_perm) row = row_perm[slot];
     ci = row_cand[row];
   } else {
     if (threadIdx.x == 0) s_c0 = find_cand(cands, ncand, (int64_t)blockIdx.x * kBlock);
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_seed(const CandDev *__restrict__ can
   const int32_t *qsa = qb.sa + qb.off[c.query];
   const double *qa_c = qacc + c.qoff - c.sp_q;
   int cnt = 0;
-  int64_t w = kEmit ? row_off[row] : 0;
+  int64_t w = kEmit ? row_off[slot] : 0;
   for (int j = c.sp_q; j <= c.ep_q; j++) {
     const double qa = qa_c[j];
     const double ie = qa + dba + c.score;
@@ -135,7 +141,42 @@ __global__ __launch_bounds__(kBlock) void k_seed(const CandDev *__restrict__ can
       cnt++;
     }
   }
-  if (!kEmit) row_count[row] = cnt;
+  if (!kEmit) row_count[slot] = cnt;
+}
+
+// Sort key of a row = (query, position in the page text): the rows of a candidate are consecutive entries of the
+// suffix array, i.e. RANDOM positions of the database, and a seed's extension reads ~5 cache lines around its
+// position - at the configs[2] database (0.9 GB of text + accessibilities) every one of them from HBM (measured:
+// 377 B fetched per seed in k_ungapped, 105 B in each k_seed pass).  Emitting the seeds of a query in the order of
+// their database positions makes neighbouring threads read neighbouring lines.  The low `shift` bits of the position
+// are left out of the key (fewer radix passes): rows of one 2^shift window stay in suffix-array order, which is all
+// the same to the caches.  The order of the seeds is free: the list is sorted by coordinates afterwards and the ties of
+// that sort are broken by the hits' own fields (k_fix_ties).
+template <class Key>
+__global__ __launch_bounds__(kBlock) void k_row_key(const CandDev *__restrict__ cands, int ncand, int64_t nrows, PageDev pg, int qmin,
+                                                    int shift, int dbits, int32_t *__restrict__ row_cand, Key *__restrict__ key,
+                                                    uint32_t *__restrict__ val) {
+  __shared__ int64_t s_row0[kBlock + 1];
+  __shared__ int s_c0;
+  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (threadIdx.x == 0) s_c0 = find_cand(cands, ncand, (int64_t)blockIdx.x * kBlock);
+  __syncthreads();
+  const int c0 = s_c0;
+  for (int t = threadIdx.x; t <= kBlock; t += kBlock) s_row0[t] = c0 + t < ncand ? cands[c0 + t].row0 : INT64_MAX;
+  __syncthreads();
+  if (row >= nrows) return;
+  int lo = 0, hi = kBlock; // last t with s_row0[t] <= row
+  while (lo < hi) {
+    const int m = (lo + hi + 1) >> 1;
+    if (s_row0[m] <= row) lo = m;
+    else hi = m - 1;
+  }
+  const int ci = c0 + lo;
+  row_cand[row] = ci;
+  const CandDev c = cands[ci];
+  const int k = c.sp_db + (int)(row - c.row0);
+  key[row] = ((Key)(uint32_t)(c.query - qmin) << dbits) | (Key)((uint32_t)pg.sa[k] >> shift);
+  val[row] = (uint32_t)row;
 }
 
 // ---------------------------------------------------------------------------- ungapped
@@ -204,19 +245,24 @@ struct QueryLds {
 // bases of the previous position and of the position next to the last pair, the type of the
 // last pair (the reference re-reads all of them).
 constexpr int kUngappedAhead = 8;
+// a hit in registers: the seed on the way in, the extended hit on the way out
+struct WalkHit {
+  int q_sp, db_sp, len, id, id_start;
+  double e_acc, e_hyb, e_tot;
+};
 template <class Q>
-__device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &tabs, HitSoA &h, int64_t x, const PageDev &pg,
+__device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &tabs, WalkHit &w, const PageDev &pg,
                                               const SearchConst &sc, const ExtOpts &o) {
   const uint8_t *ds = pg.seqs;
-  const int id = h.db_id[x];
+  const int id = w.id;
   const int64_t base = (int64_t)pg.start_pos[id] - id;
   const int64_t nacc = (int64_t)pg.nchars - pg.nseq; // floats in pg.acc / pg.cond
   const int delta = o.delta, drop = o.drop_wo_gap;
-  const int q_sp0 = h.q_sp[x], db_sp0 = h.db_sp[x], len0 = h.q_len[x];
+  const int q_sp0 = w.q_sp, db_sp0 = w.db_sp, len0 = w.len;
 
-  double min_e = h.e_tot[x], e = min_e, min_a = h.e_acc[x], a = min_a, min_h = h.e_hyb[x], hy = min_h;
+  double min_e = w.e_tot, e = min_e, min_a = w.e_acc, a = min_a, min_h = w.e_hyb, hy = min_h;
   int i = q_sp0, p = q_sp0, j = db_sp0, min_p = p, min_q = db_sp0;
-  int id_start = h.db_id_start[x], id_end = id_start + len0 - 1, min_id_start = id_start;
+  int id_start = w.id_start, id_end = id_start + len0 - 1, min_id_start = id_start;
   {
     // walk left (:55-94).  (bq, bd) = bases at (i+1, j+1); (cq, cd) = bases at (p-1, q-1), the
     // position next to the last pair; tp = rtype of the pair at (p, q)
@@ -351,14 +397,28 @@ __device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &t
       }
     }
   }
-  h.db_id_start[x] = min_id_start;
-  h.q_sp[x] = min_p;
-  h.db_sp[x] = min_q;
-  h.q_len[x] = min_r - min_p + 1;
-  h.db_len[x] = min_r - min_p + 1;
-  h.e_tot[x] = min_e;
-  h.e_acc[x] = min_a;
-  h.e_hyb[x] = min_h;
+  w.id_start = min_id_start;
+  w.q_sp = min_p;
+  w.db_sp = min_q;
+  w.len = min_r - min_p + 1;
+  w.e_tot = min_e;
+  w.e_acc = min_a;
+  w.e_hyb = min_h;
+}
+// the same on a hit of a list
+template <class Q>
+__device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &tabs, HitSoA &h, int64_t x, const PageDev &pg,
+                                              const SearchConst &sc, const ExtOpts &o) {
+  WalkHit w{h.q_sp[x], h.db_sp[x], h.q_len[x], h.db_id[x], h.db_id_start[x], h.e_acc[x], h.e_hyb[x], h.e_tot[x]};
+  ungapped_walk(qv, tabs, w, pg, sc, o);
+  h.db_id_start[x] = w.id_start;
+  h.q_sp[x] = w.q_sp;
+  h.db_sp[x] = w.db_sp;
+  h.q_len[x] = w.len;
+  h.db_len[x] = w.len;
+  h.e_tot[x] = w.e_tot;
+  h.e_acc[x] = w.e_acc;
+  h.e_hyb[x] = w.e_hyb;
 }
 
 // A workgroup takes kUngappedPer x kBlock consecutive seed hits.  Seed hits are emitted query
@@ -406,6 +466,214 @@ __global__ __launch_bounds__(kBlock) void k_ungapped(HitSoA h, int64_t n, QBatch
   }
 }
 
+// ---------------------------------------------------------------------------- seeds -> extended hits in one pass
+// Every (query SA entry, database SA entry) PAIR of a chunk of candidates is one unit of work:
+//   k_pair_key    pair p -> sort key (query, database position >> shift) and a 64-bit value
+//                 {database position : 32, candidate : 20, query entry within the candidate : 12}
+//   (radix sort of the pairs by key)
+//   k_seed_extend pair -> SeedSearch::CalcInteractionEnergy's test (seed_search.cpp:47-99); a seed is walked at once
+//                 (UngappedExtension::Run) and, if it is not above the -f threshold, kept (see SliceRec)
+//   k_collect_slices  what the workgroups kept -> the list of 64-byte records
+// Against k_seed (count) / scan / k_seed (emit) / k_ungapped / threshold compaction this never writes the seeds
+// (3.3e9 x 48 B per configs[2] step, written once, read and written by the walk, read by the compaction), and
+// neighbouring threads work at neighbouring database positions.  The list comes out in no particular order; the sort
+// behind it is total on the hits' own fields (k_fix_ties), so the result is the same.
+constexpr int kPairCandBits = 20, kPairEntBits = 12;
+static_assert(kMaxFusedCands == (1 << kPairCandBits) && kMaxFusedEntries == (1 << kPairEntBits) && kPairCandBits + kPairEntBits == 32,
+              "the value of a pair");
+constexpr int kSeqBlkShift = 5; // PageDev::blk_seq: one entry per 32 characters of the page text
+
+__global__ __launch_bounds__(kBlock) void k_blk_seq(PageDev pg, int32_t *blk_seq, int64_t nblk) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b < nblk) blk_seq[b] = seq_of(pg, (int)(b << kSeqBlkShift));
+}
+
+template <class Key>
+__global__ __launch_bounds__(kBlock) void k_pair_key(const CandDev *__restrict__ cands, const int64_t *__restrict__ pair0, int ncand,
+                                                     int64_t npairs, PageDev pg, int qmin, int shift, int dbits,
+                                                     Key *__restrict__ key, uint64_t *__restrict__ val) {
+  __shared__ int64_t s_p0[kBlock + 1];
+  __shared__ int s_c0;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (threadIdx.x == 0) { // candidate of the workgroup's first pair
+    const int64_t first = (int64_t)blockIdx.x * kBlock;
+    int lo = 0, hi = ncand - 1;
+    while (lo < hi) {
+      const int m = (lo + hi + 1) >> 1;
+      if (pair0[m] <= first) lo = m;
+      else hi = m - 1;
+    }
+    s_c0 = lo;
+  }
+  __syncthreads();
+  const int c0 = s_c0;
+  for (int t = threadIdx.x; t <= kBlock; t += kBlock) s_p0[t] = c0 + t < ncand ? pair0[c0 + t] : INT64_MAX;
+  __syncthreads();
+  if (p >= npairs) return;
+  int lo = 0, hi = kBlock; // last t with s_p0[t] <= p
+  while (lo < hi) {
+    const int m = (lo + hi + 1) >> 1;
+    if (s_p0[m] <= p) lo = m;
+    else hi = m - 1;
+  }
+  const int ci = c0 + lo;
+  const CandDev c = cands[ci];
+  const uint32_t pl = (uint32_t)(p - s_p0[lo]), qw = (uint32_t)(c.ep_q - c.sp_q + 1);
+  const uint32_t rowl = pl / qw, jrel = pl - rowl * qw;
+  const uint32_t db_sp = (uint32_t)pg.sa[c.sp_db + (int)rowl];
+  key[p] = ((Key)(uint32_t)(c.query - qmin) << dbits) | (Key)(db_sp >> shift);
+  val[p] = (uint64_t)db_sp | ((uint64_t)(uint32_t)ci << 32) | ((uint64_t)jrel << (32 + kPairCandBits));
+}
+
+// What a workgroup keeps goes to ITS slice of a sparse list (kFusePairs records, one per pair it takes: no bound to
+// check), the position from a counter in LDS; k_collect_slices then packs the used part of every slice into the list
+// proper.  (One global counter for all wavefronts - an atomic add with return per 64 pairs - serialised the whole
+// kernel: 844 ms per configs[2] step instead of 300, ~14 ns per atomic on one address.)
+struct alignas(16) SliceRec {
+  int32_t q_sp, db_sp, len, db_id, db_id_start, query;
+  double e_acc, e_hyb, e_tot;
+};
+static_assert(sizeof(SliceRec) == kSliceRecBytes, "three 16-byte stores");
+
+struct FuseArgs {
+  const CandDev *cands;
+  const uint64_t *vals;
+  int64_t npairs;
+  const double *qacc;
+  double thr;
+  SliceRec *slices;        // kFusePairs per workgroup
+  int32_t *slice_count;    // records in each slice
+  unsigned long long *nseed; // += seeds
+  int qcap;
+};
+
+__device__ __forceinline__ int pair_cand(uint64_t v) { return (int)((v >> 32) & ((1u << kPairCandBits) - 1)); }
+
+constexpr int kFusePer = kFusePairs / kBlock;
+static_assert(kFusePer * kBlock == kFusePairs, "pairs per workgroup");
+__global__ __launch_bounds__(kBlock) void k_seed_extend(FuseArgs f, QBatchDev qb, PageDev pg, SearchConst sc, ExtOpts o) {
+  extern __shared__ __align__(16) uint8_t ungapped_smem[];
+  __shared__ int32_t s_tab[kUtTotal];
+  __shared__ unsigned s_kept, s_seeds;
+  const int64_t b0 = (int64_t)blockIdx.x * kFusePairs;
+  if (b0 >= f.npairs) return;
+  const int64_t b1 = (b0 + kFusePairs < f.npairs ? b0 + kFusePairs : f.npairs) - 1;
+  if (threadIdx.x == 0) {
+    s_kept = 0;
+    s_seeds = 0;
+  }
+  for (int t = threadIdx.x; t < kUtTotal; t += kBlock)
+    s_tab[t] = t < kUtInternal   ? sc.stack37[t]
+               : t < kUtMismatch ? sc.internal37[t - kUtInternal]
+               : t < kUtInt11    ? sc.mismatchI37[t - kUtMismatch]
+                                 : sc.int11[t - kUtInt11];
+  const UngappedTabs tabs{s_tab + kUtStack, s_tab + kUtInternal, s_tab + kUtMismatch, s_tab + kUtInt11, sc.int22};
+  // the pairs are sorted by query first: one query for the whole workgroup unless it sits on a boundary
+  const int q0 = f.cands[pair_cand(f.vals[b0])].query;
+  const int nslots = qb.len[q0] + 1;
+  const bool staged = q0 == f.cands[pair_cand(f.vals[b1])].query && nslots <= f.qcap; // uniform over the workgroup
+  float *s_acc = reinterpret_cast<float *>(ungapped_smem), *s_cond = s_acc + f.qcap;
+  uint8_t *s_enc = reinterpret_cast<uint8_t *>(s_cond + f.qcap);
+  if (staged) {
+    const int64_t qo = qb.off[q0];
+    for (int t = threadIdx.x; t < nslots; t += kBlock) {
+      s_acc[t] = qb.acc[qo + t];
+      s_cond[t] = qb.cond[qo + t];
+      s_enc[t] = qb.enc[qo + t];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  SliceRec *slice = f.slices + b0;
+  unsigned nseed = 0;
+  for (int it = 0; it < kFusePer; it++) {
+    const int64_t x = b0 + (int64_t)it * kBlock + threadIdx.x;
+    bool keep = false;
+    WalkHit w{};
+    int query = 0;
+    if (x <= b1) {
+      const uint64_t v = f.vals[x];
+      const int db_sp = (int)(uint32_t)v, jrel = (int)(v >> (32 + kPairCandBits));
+      const CandDev c = f.cands[pair_cand(v)];
+      int id = pg.blk_seq[db_sp >> kSeqBlkShift];
+      while (id + 1 < pg.nseq && pg.start_pos[id + 1] <= db_sp) id++;
+      const int sp0 = pg.start_pos[id];
+      const int st = pg.seq_length[id] - (db_sp - sp0) - c.length;
+      const int64_t base = (int64_t)sp0 - id;
+      const double dba = window_acc(pg.acc + base, pg.cond + base, st, c.length, o.delta);
+      const double qa = f.qacc[c.qoff + jrel];
+      const double ie = qa + dba + c.score;
+      if (ie < 0) {
+        nseed++;
+        const int64_t qo = qb.off[c.query];
+        const double ea = qa + dba;
+        w = WalkHit{qb.sa[qo + c.sp_q + jrel], db_sp, c.length, id, st, ea, c.score, ea + c.score};
+        query = c.query;
+        if (staged) {
+          const QueryLds qv{s_enc, s_acc, s_cond};
+          ungapped_walk(qv, tabs, w, pg, sc, o);
+        } else {
+          const QueryGlobal qv{qb.enc + qo, qb.acc + qo, qb.cond + qo};
+          ungapped_walk(qv, tabs, w, pg, sc, o);
+        }
+        keep = !(w.e_tot > f.thr);
+      }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      unsigned basepos = 0;
+      if (lane == leader) basepos = atomicAdd(&s_kept, (unsigned)__popcll(mask));
+      basepos = (unsigned)__shfl((int)basepos, leader);
+      if (keep) {
+        SliceRec r;
+        r.q_sp = w.q_sp;
+        r.db_sp = w.db_sp;
+        r.len = w.len;
+        r.db_id = w.id;
+        r.db_id_start = w.id_start;
+        r.query = query;
+        r.e_acc = w.e_acc;
+        r.e_hyb = w.e_hyb;
+        r.e_tot = w.e_tot;
+        slice[basepos + (unsigned)__popcll(mask & ((1ull << lane) - 1))] = r;
+      }
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) nseed += (unsigned)__shfl_down((int)nseed, d);
+  if (lane == 0 && nseed) atomicAdd(&s_seeds, nseed);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    f.slice_count[blockIdx.x] = (int32_t)s_kept;
+    if (s_seeds) atomicAdd(f.nseed, (unsigned long long)s_seeds);
+  }
+}
+
+// slice b's records to out[off[b] ...]
+__global__ __launch_bounds__(kBlock) void k_collect_slices(const SliceRec *__restrict__ slices, const int32_t *__restrict__ count,
+                                                           const int64_t *__restrict__ off, HitRec *__restrict__ out) {
+  const int n = count[blockIdx.x];
+  const SliceRec *src = slices + (int64_t)blockIdx.x * kFusePairs;
+  HitRec *dst = out + off[blockIdx.x];
+  for (int t = threadIdx.x; t < n; t += kBlock) {
+    const SliceRec a = src[t];
+    HitRec r;
+    r.q_sp = a.q_sp;
+    r.db_sp = a.db_sp;
+    r.q_len = a.len;
+    r.db_len = a.len;
+    r.db_id = a.db_id;
+    r.db_id_start = a.db_id_start;
+    r.query = a.query;
+    r.pad0 = 0;
+    r.e_acc = a.e_acc;
+    r.e_hyb = a.e_hyb;
+    r.e_tot = a.e_tot;
+    r.pad1 = 0;
+    dst[t] = r;
+  }
+}
+
 // ------------------------------------------------------------------- sort keys / gather
 
 __global__ __launch_bounds__(kBlock) void k_make_keys(HitSoA h, int64_t n, uint64_t *k_energy, uint32_t *k_len,
@@ -413,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_make_keys(HitSoA h, int64_t n, uint6
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   // compare(): db_sp asc, q_sp asc, db_len desc, q_len desc (rna_interaction_search.cpp:45-55);
-  // ties are then broken by energy asc and input order (DESIGN.md "total order")
+  // ties are then broken by energy asc, its two parts and input order (DESIGN.md "total order")
   const uint64_t eb = (uint64_t)__double_as_longlong(h.e_tot[i]);
   k_energy[i] = (eb >> 63) ? ~eb : (eb | 0x8000000000000000ull);
   k_len[i] = ((uint32_t)(0xFFFF - US(h.db_len[i])) << 16) | (uint32_t)(0xFFFF - US(h.q_len[i]));
@@ -459,8 +727,16 @@ __global__ __launch_bounds__(kBlock) void k_make_packed_keys_recs(const HitRec *
 }
 
 constexpr int kMaxTieRun = 4096;
+// monotone map of a double onto unsigned integers
+__device__ __forceinline__ uint64_t order_bits(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+// Runs of identical coordinates are put in (energy, hybridization part, accessibility part, input index) order: two
+// hits still tied after the three energies are identical records, so the result does not depend on the order in which
+// the seeds were produced (chunks of candidates, rows sorted by database position).
 __global__ __launch_bounds__(kBlock) void k_fix_ties(const uint64_t *__restrict__ key, uint64_t *e, uint32_t *perm, int64_t n,
-                                                     int32_t *too_long) {
+                                                     const HitRec *__restrict__ recs, int32_t *too_long) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n || i + 1 >= n) return;
   const uint64_t k = key[i];
@@ -471,11 +747,19 @@ __global__ __launch_bounds__(kBlock) void k_fix_ties(const uint64_t *__restrict_
     *too_long = 1;
     return;
   }
-  for (int64_t a = i + 1; a < end; a++) { // insertion sort by (energy, input index); the input is in index order
+  auto after = [&](uint64_t eb, uint32_t pb, uint64_t ea, uint32_t pa) { // (eb, pb) sorts after (ea, pa)
+    if (eb != ea) return eb > ea;
+    const uint64_t hb = order_bits(recs[pb].e_hyb), ha = order_bits(recs[pa].e_hyb);
+    if (hb != ha) return hb > ha;
+    const uint64_t ab = order_bits(recs[pb].e_acc), aa = order_bits(recs[pa].e_acc);
+    if (ab != aa) return ab > aa;
+    return pb > pa;
+  };
+  for (int64_t a = i + 1; a < end; a++) { // insertion sort; the input is in index order
     const uint64_t ea = e[a];
     const uint32_t pa = perm[a];
     int64_t b = a - 1;
-    while (b >= i && (e[b] > ea || (e[b] == ea && perm[b] > pa))) {
+    while (b >= i && after(e[b], perm[b], ea, pa)) {
       e[b + 1] = e[b];
       perm[b + 1] = perm[b];
       b--;
@@ -483,6 +767,11 @@ __global__ __launch_bounds__(kBlock) void k_fix_ties(const uint64_t *__restrict_
     e[b + 1] = ea;
     perm[b + 1] = pa;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_order_keys(const double *__restrict__ v, int64_t n, uint64_t *__restrict__ key) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) key[i] = order_bits(v[i]);
 }
 
 template <class T> __global__ __launch_bounds__(kBlock) void k_gather(const T *src, const uint32_t *idx, T *dst, int64_t n) {
@@ -692,19 +981,65 @@ hipError_t launch_seed_qacc(const CandDev *cands, int32_t ncand, int64_t nq_entr
   hipLaunchKernelGGL(k_seed_qacc, grid_for(nq_entries), dim3(kBlock), 0, s, cands, ncand, nq_entries, qb, delta, qacc);
   return hipGetLastError();
 }
+hipError_t launch_row_keys(const CandDev *cands, int32_t ncand, int64_t nrows, const PageDev &pg, int qmin, int shift, int dbits,
+                           bool wide, int32_t *row_cand, void *key, uint32_t *val, hipStream_t s) {
+  if (nrows <= 0) return hipSuccess;
+  if (wide)
+    hipLaunchKernelGGL(k_row_key<uint64_t>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, pg, qmin, shift, dbits, row_cand,
+                       (uint64_t *)key, val);
+  else
+    hipLaunchKernelGGL(k_row_key<uint32_t>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, pg, qmin, shift, dbits, row_cand,
+                       (uint32_t *)key, val);
+  return hipGetLastError();
+}
 hipError_t launch_seed_count(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
-                             int delta, const double *qacc, int32_t *row_count, int32_t *row_cand, hipStream_t s) {
+                             int delta, const double *qacc, int32_t *row_count, int32_t *row_cand, const uint32_t *row_perm,
+                             hipStream_t s) {
   if (nrows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_seed<false>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, qb, pg, delta, qacc, row_count,
-                     row_cand, (const int64_t *)nullptr, HitSoA{});
+                     row_cand, (const int64_t *)nullptr, HitSoA{}, row_perm);
   return hipGetLastError();
 }
 hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
                             int delta, const double *qacc, const int32_t *row_cand, const int64_t *row_off, HitSoA hits,
-                            hipStream_t s) {
+                            const uint32_t *row_perm, hipStream_t s) {
   if (nrows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_seed<true>, grid_for(nrows), dim3(kBlock), 0, s, cands, ncand, nrows, qb, pg, delta, qacc,
-                     (int32_t *)nullptr, const_cast<int32_t *>(row_cand), row_off, hits);
+                     (int32_t *)nullptr, const_cast<int32_t *>(row_cand), row_off, hits, row_perm);
+  return hipGetLastError();
+}
+hipError_t launch_blk_seq(const PageDev &pg, int32_t *blk_seq, hipStream_t s) {
+  const int64_t nblk = blk_seq_entries(pg.nchars);
+  hipLaunchKernelGGL(k_blk_seq, grid_for(nblk), dim3(kBlock), 0, s, pg, blk_seq, nblk);
+  return hipGetLastError();
+}
+hipError_t launch_pair_keys(const CandDev *cands, const int64_t *pair0, int32_t ncand, int64_t npairs, const PageDev &pg, int qmin,
+                            int shift, int dbits, bool wide, void *key, uint64_t *val, hipStream_t s) {
+  if (npairs <= 0) return hipSuccess;
+  if (wide)
+    hipLaunchKernelGGL(k_pair_key<uint64_t>, grid_for(npairs), dim3(kBlock), 0, s, cands, pair0, ncand, npairs, pg, qmin, shift, dbits,
+                       (uint64_t *)key, val);
+  else
+    hipLaunchKernelGGL(k_pair_key<uint32_t>, grid_for(npairs), dim3(kBlock), 0, s, cands, pair0, ncand, npairs, pg, qmin, shift, dbits,
+                       (uint32_t *)key, val);
+  return hipGetLastError();
+}
+hipError_t launch_seed_extend(const CandDev *cands, const uint64_t *vals, int64_t npairs, const QBatchDev &qb, const PageDev &pg,
+                              const SearchConst &sc, ExtOpts o, const double *qacc, double thr, int max_query_len, void *slices,
+                              int32_t *slice_count, uint64_t *nseed, hipStream_t s) {
+  if (npairs <= 0) return hipSuccess;
+  int qcap = (max_query_len + 1 + 3) & ~3; // as launch_ungapped
+  if (qcap > 7168) qcap = 7168;
+  FuseArgs f{cands, vals, npairs, qacc, thr, static_cast<SliceRec *>(slices), slice_count, reinterpret_cast<unsigned long long *>(nseed),
+             qcap};
+  hipLaunchKernelGGL(k_seed_extend, dim3((unsigned)fused_slices(npairs)), dim3(kBlock), (size_t)qcap * 9, s, f, qb, pg, sc, o);
+  return hipGetLastError();
+}
+hipError_t launch_collect_slices(const void *slices, const int32_t *slice_count, const int64_t *slice_off, int64_t nslices, HitRec *out,
+                                 hipStream_t s) {
+  if (nslices <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_collect_slices, dim3((unsigned)nslices), dim3(kBlock), 0, s, static_cast<const SliceRec *>(slices), slice_count,
+                     slice_off, out);
   return hipGetLastError();
 }
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc, ExtOpts o,
@@ -730,10 +1065,15 @@ hipError_t launch_make_packed_keys(const HitSoA &hits, int64_t n, const PackedKe
   hipLaunchKernelGGL(k_make_packed_keys, grid_for(n), dim3(kBlock), 0, s, hits, n, f, key, k_energy, idx);
   return hipGetLastError();
 }
-hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, int32_t *too_long,
-                           hipStream_t s) {
+hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, const HitRec *recs,
+                           int32_t *too_long, hipStream_t s) {
   if (n <= 1) return hipSuccess;
-  hipLaunchKernelGGL(k_fix_ties, grid_for(n), dim3(kBlock), 0, s, key_sorted, e_sorted, perm, n, too_long);
+  hipLaunchKernelGGL(k_fix_ties, grid_for(n), dim3(kBlock), 0, s, key_sorted, e_sorted, perm, n, recs, too_long);
+  return hipGetLastError();
+}
+hipError_t launch_order_keys(const double *v, int64_t n, uint64_t *key, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_order_keys, grid_for(n), dim3(kBlock), 0, s, v, n, key);
   return hipGetLastError();
 }
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s) {

@@ -48,6 +48,7 @@ struct PageDev {
   const uint8_t *seqs; // page text: reversed sequences, 0 after each
   const int32_t *sa;
   const int32_t *sa_seq;  // sequence that SA entry k lies in (GetSeqIdAndStart's search, done once per page)
+  const int32_t *blk_seq; // sequence that character 32 b of the page text lies in (b = 0 .. (nchars - 1) / 32)
   const int32_t *start_pos;
   const int32_t *seq_length;
   const float *acc;  // padded to L per sequence; sequence id at start_pos[id] - id
@@ -87,16 +88,25 @@ struct ExtOpts {
 };
 
 // ---- seeds ----
+// blk_seq for a page (PageDev::blk_seq, blk_seq_entries(nchars) values)
+inline int64_t blk_seq_entries(int64_t nchars) { return (nchars >> 5) + 1; }
+hipError_t launch_blk_seq(const PageDev &pg, int32_t *blk_seq, hipStream_t s);
 // sa_seq[k] for every SA entry of a page
 hipError_t launch_sa_seq(const PageDev &pg, int32_t *sa_seq, hipStream_t s);
 // qacc[c.qoff + t] = accessibility energy of the query window of candidate c at its SA entry sp_q + t
 hipError_t launch_seed_qacc(const CandDev *cands, int32_t ncand, int64_t nq_entries, const QBatchDev &qb, int delta, double *qacc,
                             hipStream_t s);
+// row_perm (optional, both passes alike): the order in which the rows are taken - launch_row_keys gives every row its
+// candidate (row_cand) and the key ((query - qmin) << dbits | position in the page text >> shift; 64-bit keys if `wide`,
+// else 32-bit) to sort the rows by, val = the row
+hipError_t launch_row_keys(const CandDev *cands, int32_t ncand, int64_t nrows, const PageDev &pg, int qmin, int shift, int dbits,
+                           bool wide, int32_t *row_cand, void *key, uint32_t *val, hipStream_t s);
 hipError_t launch_seed_count(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
-                             int delta, const double *qacc, int32_t *row_count, int32_t *row_cand, hipStream_t s);
+                             int delta, const double *qacc, int32_t *row_count, int32_t *row_cand, const uint32_t *row_perm,
+                             hipStream_t s);
 hipError_t launch_seed_emit(const CandDev *cands, int32_t ncand, int64_t nrows, const QBatchDev &qb, const PageDev &pg,
                             int delta, const double *qacc, const int32_t *row_cand, const int64_t *row_off, HitSoA hits,
-                            hipStream_t s);
+                            const uint32_t *row_perm, hipStream_t s);
 // ---- ungapped ----
 hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const PageDev &pg, const SearchConst &sc,
                            ExtOpts o, int max_query_len, hipStream_t s);
@@ -110,8 +120,7 @@ hipError_t launch_make_packed_keys(const HitSoA &hits, int64_t n, const PackedKe
                                    uint32_t *idx, hipStream_t s);
 // after the stable sort by the packed key: runs of equal keys -> (energy, input index) order; *too_long is
 // set if a run is longer than the kernel handles (the caller then sorts by the four keys instead)
-hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, int32_t *too_long,
-                           hipStream_t s);
+hipError_t launch_order_keys(const double *v, int64_t n, uint64_t *key, hipStream_t s); // monotone u64 image of doubles
 hipError_t launch_make_keys(const HitSoA &hits, int64_t n, uint64_t *k_energy, uint32_t *k_len, uint32_t *k_qsp,
                             uint64_t *k_pos, uint32_t *idx, hipStream_t s);
 hipError_t launch_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n, hipStream_t s);
@@ -130,6 +139,24 @@ struct alignas(16) HitRec {
   int64_t pad1;
 };
 static_assert(sizeof(HitRec) == 64, "one cache line half, two per 128-byte line");
+// Seeds to extended hits in one pass over the (query SA entry, database SA entry) pairs of a chunk of candidates
+// (search_kernels.hip, "seeds -> extended hits in one pass").  pair0[c] = first pair of candidate c; at most
+// kMaxFusedCands candidates of at most kMaxFusedEntries query entries each.
+constexpr int64_t kMaxFusedCands = 1 << 20, kMaxFusedEntries = 1 << 12;
+hipError_t launch_pair_keys(const CandDev *cands, const int64_t *pair0, int32_t ncand, int64_t npairs, const PageDev &pg, int qmin,
+                            int shift, int dbits, bool wide, void *key, uint64_t *val, hipStream_t s);
+// A workgroup takes kFusePairs pairs and keeps what survives in its slice of `slices` (kFusePairs records of
+// kSliceRecBytes each), slice_count[b] of them; *nseed += seeds.  launch_collect_slices packs the slices into `out`
+// (slice b at slice_off[b] = the exclusive scan of the counts).
+constexpr int kFusePairs = 2048, kSliceRecBytes = 48;
+inline int64_t fused_slices(int64_t npairs) { return (npairs + kFusePairs - 1) / kFusePairs; }
+hipError_t launch_seed_extend(const CandDev *cands, const uint64_t *vals, int64_t npairs, const QBatchDev &qb, const PageDev &pg,
+                              const SearchConst &sc, ExtOpts o, const double *qacc, double thr, int max_query_len, void *slices,
+                              int32_t *slice_count, uint64_t *nseed, hipStream_t s);
+hipError_t launch_collect_slices(const void *slices, const int32_t *slice_count, const int64_t *slice_off, int64_t nslices, HitRec *out,
+                                 hipStream_t s);
+hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, const HitRec *recs,
+                           int32_t *too_long, hipStream_t s);
 hipError_t launch_gather_hits_to_recs(const HitSoA &src, const uint32_t *idx, HitRec *dst, int64_t n, hipStream_t s);
 // idx == nullptr: in order
 hipError_t launch_gather_recs_to_hits(const HitRec *src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);

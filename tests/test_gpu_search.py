@@ -102,25 +102,47 @@ def test_sub_batching_is_transparent(ctx, golden_dir, monkeypatch):
         db.close()
 
 
-def test_candidate_chunks_are_transparent(ctx, golden_dir, monkeypatch):
+SEED_PATHS = {
+    "fused": {},                                  # pairs sorted by database position, seeds walked where they are found
+    "rows": {"PRB_SEED_FUSED": "0"},              # rows sorted by database position, seed list / walk / compaction
+    "sa_order": {"PRB_SEED_ROW_SHIFT": "-1"},     # rows in suffix-array order (the reference's emission order)
+    "fused_exact": {"PRB_SEED_ROW_SHIFT": "0"},
+    "fused_coarse": {"PRB_SEED_ROW_SHIFT": "14"},
+}
+
+
+def test_candidate_chunks_and_seed_paths_are_transparent(ctx, golden_dir, monkeypatch):
     """A query whose candidate pairs exceed the budget is cut into chunks of candidates for the seed / ungapped / -f
     part (it used to be submitted whole, pools sized from its seed count); the sort and the filters see the
-    union.  Tiny chunks on the 3-page case: every stage identical to the unchunked run."""
+    union.  And that part exists in three forms (SEED_PATHS) that hand the sort the same hits in different orders.
+    Tiny chunks on the 3-page case: every stage identical - bit for bit, base pairs included - whatever the path and
+    the chunking (the sort's order is total on the hits' own fields)."""
     from priblast_amd import capi
     names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "mix_q.fa"))
     db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
     qb = capi.QBatch(ctx, seqs, db.repeat_flag)
     qb.accessibility(db.W, db.delta)
+    knobs = ("PRB_SEARCH_CHUNK_PAIRS", "PRB_SEED_FUSED", "PRB_SEED_ROW_SHIFT")
+
+    def run(stage, env):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return [capi.search_page(ctx, qb, db, p, capi.default_opts(output_style=1), stage) for p in range(db.npages)]
+
     try:
         for stage in (1, 2, 3):
-            monkeypatch.delenv("PRB_SEARCH_CHUNK_PAIRS", raising=False)
-            ref = [capi.search_page(ctx, qb, db, p, capi.default_opts(output_style=1), stage) for p in range(db.npages)]
-            monkeypatch.setenv("PRB_SEARCH_CHUNK_PAIRS", "300")
-            got = [capi.search_page(ctx, qb, db, p, capi.default_opts(output_style=1), stage) for p in range(db.npages)]
-            for (h1, b1, c1), (h2, b2, c2) in zip(ref, got):
-                assert c1 == c2 and np.array_equal(h1, h2) and np.array_equal(b1, b2), stage
+            ref = run(stage, SEED_PATHS["sa_order"])
+            for name, env in SEED_PATHS.items():
+                for chunk in (None, "300"):
+                    got = run(stage, dict(env, **({"PRB_SEARCH_CHUNK_PAIRS": chunk} if chunk else {})))
+                    for (h1, b1, c1), (h2, b2, c2) in zip(ref, got):
+                        assert c1 == c2 and np.array_equal(h1, h2) and np.array_equal(b1, b2), (stage, name, chunk)
         assert sum(r[2][0] for r in ref) > 1000
     finally:
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
         qb.close()
         db.close()
 
@@ -139,7 +161,7 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
-                                 "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_LANE"])
+                                 "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_LANE", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
     LDS kernel (normally only the extensions that outgrow the smaller tiers) must give the same
@@ -147,7 +169,8 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     cascade with the experimental lane-per-hit kernel in front (PRB_GAPPED_LANE); likewise re-extending the final
     hits (all, or those with more than one traced pair per side) instead of reading their
     base pairs from the trace slots of the extension pass; likewise the general four-key sort
-    instead of the one-key sort + tie pass."""
+    instead of the one-key sort + tie pass; likewise the seeds written as a list and extended in a second pass
+    (rows by database position, or in the reference's suffix-array order) instead of the one-pass form."""
     from priblast_amd import capi
     env, _, value = env.partition("=")
     for tag in ("c1", "mix", "quirk"):
