@@ -1333,6 +1333,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
                                   tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream));
         int64_t rest = 0;
         if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
+        if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[tier %d] hits %lld, go on %lld\n", tier, (long long)m, (long long)rest);
         cur = bufs[nb];
         nb ^= 1;
         m = rest;
