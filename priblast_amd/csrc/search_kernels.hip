@@ -11,6 +11,8 @@
 // float-derived accessibilities, summed in the reference's order (-ffp-contract=off).
 #include "search_kernels.hpp"
 
+#include <cstdlib>
+
 #include "../../include/priblast_hip.h"
 
 #include "search_device.hpp"
@@ -244,14 +246,13 @@ struct QueryLds {
 // needs again later is carried in registers - the accessibility of the previous position, the
 // bases of the previous position and of the position next to the last pair, the type of the
 // last pair (the reference re-reads all of them).
-constexpr int kUngappedAhead = 8;
 // a hit in registers: the seed on the way in, the extended hit on the way out
 struct WalkHit {
   int q_sp, db_sp, len, id, id_start;
   double e_acc, e_hyb, e_tot;
 };
-template <class Q>
-__device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &tabs, WalkHit &w, const PageDev &pg,
+template <int kUngappedAhead, class Q>
+__device__ __forceinline__ void ungapped_walk_reg(const Q &qv, const UngappedTabs &tabs, WalkHit &w, const PageDev &pg,
                                               const SearchConst &sc, const ExtOpts &o) {
   const uint8_t *ds = pg.seqs;
   const int id = w.id;
@@ -410,7 +411,7 @@ template <class Q>
 __device__ __forceinline__ void ungapped_walk(const Q &qv, const UngappedTabs &tabs, HitSoA &h, int64_t x, const PageDev &pg,
                                               const SearchConst &sc, const ExtOpts &o) {
   WalkHit w{h.q_sp[x], h.db_sp[x], h.q_len[x], h.db_id[x], h.db_id_start[x], h.e_acc[x], h.e_hyb[x], h.e_tot[x]};
-  ungapped_walk(qv, tabs, w, pg, sc, o);
+  ungapped_walk_reg<8>(qv, tabs, w, pg, sc, o);
   h.db_id_start[x] = w.id_start;
   h.q_sp[x] = w.q_sp;
   h.db_sp[x] = w.db_sp;
@@ -551,6 +552,7 @@ __device__ __forceinline__ int pair_cand(uint64_t v) { return (int)((v >> 32) & 
 
 constexpr int kFusePer = kFusePairs / kBlock;
 static_assert(kFusePer * kBlock == kFusePairs, "pairs per workgroup");
+template <int kAhead>
 __global__ __launch_bounds__(kBlock) void k_seed_extend(FuseArgs f, QBatchDev qb, PageDev pg, SearchConst sc, ExtOpts o) {
   extern __shared__ __align__(16) uint8_t ungapped_smem[];
   __shared__ int32_t s_tab[kUtTotal];
@@ -611,10 +613,10 @@ __global__ __launch_bounds__(kBlock) void k_seed_extend(FuseArgs f, QBatchDev qb
         query = c.query;
         if (staged) {
           const QueryLds qv{s_enc, s_acc, s_cond};
-          ungapped_walk(qv, tabs, w, pg, sc, o);
+          ungapped_walk_reg<kAhead>(qv, tabs, w, pg, sc, o);
         } else {
           const QueryGlobal qv{qb.enc + qo, qb.acc + qo, qb.cond + qo};
-          ungapped_walk(qv, tabs, w, pg, sc, o);
+          ungapped_walk_reg<kAhead>(qv, tabs, w, pg, sc, o);
         }
         keep = !(w.e_tot > f.thr);
       }
@@ -1032,7 +1034,8 @@ hipError_t launch_seed_extend(const CandDev *cands, const uint64_t *vals, int64_
   if (qcap > 7168) qcap = 7168;
   FuseArgs f{cands, vals, npairs, qacc, thr, static_cast<SliceRec *>(slices), slice_count, reinterpret_cast<unsigned long long *>(nseed),
              qcap};
-  hipLaunchKernelGGL(k_seed_extend, dim3((unsigned)fused_slices(npairs)), dim3(kBlock), (size_t)qcap * 9, s, f, qb, pg, sc, o);
+  // (4, 5 or 6 positions fetched ahead instead of 8: the same 273-290 ms per configs[2] step)
+  hipLaunchKernelGGL(k_seed_extend<8>, dim3((unsigned)fused_slices(npairs)), dim3(kBlock), (size_t)qcap * 9, s, f, qb, pg, sc, o);
   return hipGetLastError();
 }
 hipError_t launch_collect_slices(const void *slices, const int32_t *slice_count, const int64_t *slice_off, int64_t nslices, HitRec *out,
