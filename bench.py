@@ -86,10 +86,27 @@ def measured_traffic(units_per_launch):
 
 
 def host_cores():
+    """CPUs this process may keep busy: the affinity mask, cut down by the cgroup's CPU bandwidth limit (a GPU box
+    shows 256 hardware threads under a quota of 16 CPUs; more busy threads than that and the kernel parks all of
+    them - the thread feeding the GPU included - for the rest of every 100 ms period)"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                quota, period = int(f.read()), int(g.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def result_rows(path):
@@ -158,9 +175,10 @@ def cpu_baseline(a, ctx, workdir, qnames, qseqs, log):
            "sample": f"first {n} of the {len(qseqs)} queries (one per OpenMP thread) vs the first {nsub} of the {a.db_seqs} database "
                      f"sequences built as their own database; value = measured_on_fraction / db_scale_factor",
            "measured_on_fraction": {"queries_per_s": n / dt, "wall_s": round(dt, 2), "result_lines": nhits, "db_seqs": nsub},
-           "db_scale_factor": frac, "host_cores": host_cores(), "threads_used": threads,
-           "all_threads_note": "round 1 measured the reference at 0.66 queries/s on all 256 hardware threads vs 1.0-1.2 on 32 "
-                               "(C2 workload, profiles/README.md): 32 threads is the favourable setting for it"}
+           "db_scale_factor": frac, "host_cores": host_cores(), "hardware_threads_visible": os.cpu_count(), "threads_used": threads,
+           "all_threads_note": "host_cores = the CPUs the process may keep busy (affinity mask and cgroup CPU quota: 16 on a one-GPU box "
+                               "that shows 256 hardware threads); one thread per such CPU, at most 32.  Round 1 measured the reference at "
+                               "0.66 queries/s on all 256 visible threads vs 1.0-1.2 on 32 (C2 workload, profiles/README.md)"}
     # The drop-in command on the very same sample and database, every result line (Id column aside), against
     # BOTH builds of the reference: its strict-IEEE build (-ffp-contract=off) is the parity target and must
     # agree line for line as printed; the as-shipped build (FMA contraction) is the one timed above, and its
@@ -221,7 +239,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # host threads for the per-query host work (suffix arrays, seed DFS, line formatting): share the box among the ranks
-    os.environ.setdefault("PRB_HOST_THREADS", str(max(8, min(32, host_cores() // max(world, 1)))))
+    # per pool of host threads (seed DFS, result lines: two are busy at a time), of this rank's share of the CPUs
+    os.environ.setdefault("PRB_HOST_THREADS", str(max(2, min(32, host_cores() // (2 * max(world, 1))))))
     torch.cuda.set_device(local)
     multi = world > 1 or a.force_comm
     if world > 1:

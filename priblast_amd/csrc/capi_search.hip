@@ -20,6 +20,7 @@
 
 #include "../../include/priblast_hip.h"
 #include "context.hpp"
+#include "cpu_budget.hpp"
 #include "db_format.hpp"
 #include "encoder.hpp"
 #include "hitset.hpp"
@@ -48,12 +49,33 @@ struct SearchWs {
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
       scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, laneScratch, pair0;
   std::vector<int64_t> pair0_host;
+  // results leave on a stream of their own: the next sub-batch does not queue behind 60 MB over PCIe
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t packed_ready = nullptr, copy_done = nullptr;
+  bool copy_pending = false;
+  int copy_init() {
+    if (copy_stream) return PRB_OK;
+    if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&packed_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&copy_done, hipEventDisableTiming) != hipSuccess) {
+      set_error("hipStreamCreate / hipEventCreate failed (result copies)");
+      return PRB_ERR_HIP;
+    }
+    return PRB_OK;
+  }
   PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
                       &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &laneScratch, &pair0})
       b->release();
+    if (copy_stream) {
+      (void)hipStreamSynchronize(copy_stream);
+      (void)hipStreamDestroy(copy_stream);
+      (void)hipEventDestroy(packed_ready);
+      (void)hipEventDestroy(copy_done);
+      copy_stream = nullptr;
+    }
     pinned.release();
     cand_pinned.release();
     for (int i = 0; i < 2; i++) {
@@ -79,6 +101,10 @@ struct Drainer {
   std::condition_variable cv;
   std::deque<Job> jobs;
   bool busy[2] = {false, false}, stop = false, failed = false;
+  // what the whole search is expected to deliver (extrapolated by the submitting thread from the queries done so far):
+  // the vectors then grow once instead of doubling five times - each doubling of a list of 1e7 hits is a fresh 1 GB
+  // mapping, page faults and a copy, on a thread the next staging slot waits for
+  std::atomic<size_t> hint_hits{0}, hint_bp{0};
 
   Drainer(std::vector<prb_hit> *h, std::vector<int32_t> *b, PinnedBuf *ph, PinnedBuf *pb)
       : hits(h), bp(b), pin_hits(ph), pin_bp(pb) {}
@@ -101,11 +127,11 @@ struct Drainer {
       if (hipEventSynchronize(ev[j.slot]) != hipSuccess) failed = true;
       const prb_hit *src = static_cast<const prb_hit *>(pin_hits[j.slot].p);
       if (hits->capacity() < hits->size() + (size_t)j.nhits)
-        hits->reserve(std::max(2 * hits->capacity(), hits->size() + (size_t)j.nhits));
+        hits->reserve(std::max({2 * hits->capacity(), hits->size() + (size_t)j.nhits, hint_hits.load()}));
       hits->insert(hits->end(), src, src + j.nhits);
       const int32_t *bsrc = static_cast<const int32_t *>(pin_bp[j.slot].p);
       if (bp->capacity() < bp->size() + (size_t)j.nbp_ints)
-        bp->reserve(std::max(2 * bp->capacity(), bp->size() + (size_t)j.nbp_ints));
+        bp->reserve(std::max({2 * bp->capacity(), bp->size() + (size_t)j.nbp_ints, hint_bp.load()}));
       bp->insert(bp->end(), bsrc, bsrc + j.nbp_ints);
       {
         std::lock_guard<std::mutex> lk(m);
@@ -237,11 +263,11 @@ struct prb_qbatch {
 namespace prb {
 // Host threads for the per-query host work (suffix arrays, seed DFS).  An explicit count,
 // because launchers such as torchrun export OMP_NUM_THREADS=1: PRB_HOST_THREADS, else
-// min(32, hardware threads).
+// half of the CPUs the process may keep busy (cpu_budget.hpp), at most 32.
 static int host_threads(int work_items) {
   static const int cap = [] {
     const char *e = getenv("PRB_HOST_THREADS");
-    int n = e ? atoi(e) : std::min(32, (int)std::max(1u, std::thread::hardware_concurrency()));
+    int n = e ? atoi(e) : default_host_threads();
     return std::max(1, n);
   }();
   return std::max(1, std::min(cap, work_items));
@@ -1369,6 +1395,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
 
   // ---- base pairs of the survivors: from the trace slots of the extension pass; the few hits
   // the slots cannot describe (wave-kernel hits, chains longer than a slot) are extended again ----
+  if ((rc = w.copy_init())) return rc;
+  if (w.copy_pending) { // the last results' copy still reads the buffers that are written next
+    PRB_HIP(hipStreamWaitEvent(ctx->stream, w.copy_done, 0));
+    w.copy_pending = false;
+  }
   if ((rc = ctx->time_begin())) return rc;
   if ((rc = w.bpCount.ensure((size_t)(nfin + 1) * 4)) || (rc = w.bpOff.ensure((size_t)(nfin + 1) * 8)) ||
       (rc = w.tierFin.ensure((size_t)nfin)) || (rc = w.ntraceFin.ensure((size_t)nfin * 4)))
@@ -1455,15 +1486,19 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       PRB_HIP(launch_pack_hits(F, nfin, w.bpCount.as<int32_t>(), w.bpOff.as<int64_t>(), bp_base_pairs, w.packed.p, ctx->stream));
       bp_src = w.bpOut.as<int32_t>();
     }
-    PRB_HIP(hipMemcpyAsync(w.pin_hits[slot].p, w.packed.p, (size_t)nfin * sizeof(prb_hit), hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipEventRecord(w.packed_ready, ctx->stream));
+    PRB_HIP(hipStreamWaitEvent(w.copy_stream, w.packed_ready, 0));
+    PRB_HIP(hipMemcpyAsync(w.pin_hits[slot].p, w.packed.p, (size_t)nfin * sizeof(prb_hit), hipMemcpyDeviceToHost, w.copy_stream));
     if (nbp_ints)
-      PRB_HIP(hipMemcpyAsync(w.pin_bp[slot].p, bp_src, (size_t)nbp_ints * 4, hipMemcpyDeviceToHost, ctx->stream));
+      PRB_HIP(hipMemcpyAsync(w.pin_bp[slot].p, bp_src, (size_t)nbp_ints * 4, hipMemcpyDeviceToHost, w.copy_stream));
+    PRB_HIP(hipEventRecord(w.copy_done, w.copy_stream));
+    w.copy_pending = true;
     if (hs->on_device) { // device copies for the final hit gather (prb_gather_hits): no re-upload later
       if ((rc = hs->d_hits.append(w.packed.p, (size_t)nfin * sizeof(prb_hit), ctx->stream)) ||
           (rc = hs->d_bp.append(bp_src, (size_t)nbp_ints * 4, ctx->stream)))
         return rc;
     }
-    PRB_HIP(hipEventRecord(hs->drain->ev[slot], ctx->stream));
+    PRB_HIP(hipEventRecord(hs->drain->ev[slot], w.copy_stream));
     hs->drain->submit(Drainer::Job{slot, nfin, nbp_ints});
     hs->hits_total += nfin;
     hs->bp_ints_total += nbp_ints;
@@ -1654,6 +1689,11 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     // the pinned candidates are reused by the next sub-batch: their upload must be over
     if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;
     q0 = q1;
+    if (q0 < nq) { // with a tenth to spare
+      const double scale = 1.1 * (double)nq / (double)q0;
+      drain.hint_hits = (size_t)((double)hs->counts[2] * scale);
+      drain.hint_bp = (size_t)((double)hs->bp_ints_total * scale);
+    }
   }
   producer.join();
   {

@@ -1,6 +1,8 @@
 // Result lines of `ris` (SaveMyResults, rna_interaction_search.cpp:322-369).  See output.hpp.
 #include "output.hpp"
 
+#include "cpu_budget.hpp"
+
 #include <unistd.h>
 
 #include <algorithm>
@@ -13,8 +15,7 @@ namespace prb {
 
 int format_threads() {
   if (const char *e = std::getenv("PRB_HOST_THREADS")) return std::max(1, std::atoi(e));
-  const unsigned hw = std::thread::hardware_concurrency();
-  return (int)std::min(32u, std::max(1u, hw));
+  return default_host_threads();
 }
 
 namespace {
