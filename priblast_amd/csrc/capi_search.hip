@@ -1087,6 +1087,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       }
       if ((rc = ctx->time_end("ungapped", 1))) return rc;
       hs->counts[0] += (int64_t)cnt[0];
+      if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[pairs] cands %d pairs %lld seeds %lld kept %lld\n", nc, (long long)np, (long long)cnt[0], (long long)cnt[1]);
       m1 += (int64_t)cnt[1];
       c0 = c1;
       if (m1 > (int64_t)UINT32_MAX - 16) {

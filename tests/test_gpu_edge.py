@@ -219,6 +219,36 @@ def test_query_longer_than_the_lds_staging(ctx, oracle, golden_dir):
         odb.close()
 
 
+def test_candidate_with_more_query_entries_than_a_pair_value_holds(ctx, oracle, golden_dir, monkeypatch):
+    """A 5,000 nt poly-G query: its seed candidates have ~5,000 query suffix-array entries each, more than the 4,096 the
+    one-pass form's pair value has bits for, so those chunks take the list form (search_range's `fuse = false`); a
+    mixed query in the same batch takes the one-pass form.  Both against the oracle, and the same with the list form
+    forced for everything."""
+    from priblast_amd import capi
+    rng = random.Random(11)
+    seqs = ["G" * 5000, "".join(rng.choice("ACGU") for _ in range(300)) + "GGGGGGGGGG" + "".join(rng.choice("ACGU") for _ in range(300))]
+    db = capi.Db(ctx, os.path.join(golden_dir, "c1db"))
+    odb = oracle.Db(os.path.join(golden_dir, "c1db"))
+    qb = capi.QBatch(ctx, seqs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        hits, bp, counts = capi.search_page(ctx, qb, db, 0, capi.default_opts(output_style=1))
+        monkeypatch.setenv("PRB_SEED_FUSED", "0")
+        hits2, bp2, counts2 = capi.search_page(ctx, qb, db, 0, capi.default_opts(output_style=1))
+        monkeypatch.delenv("PRB_SEED_FUSED")
+        assert counts == counts2 and np.array_equal(hits, hits2) and np.array_equal(bp, bp2)
+        assert counts[0] > 5000  # seeds: the poly-G entries x the database's C/U runs
+        for q, s in enumerate(seqs):
+            _, _, gap = odb.stages(s, 0)
+            ref = [(h["db_sp"], h["q_sp"], h["db_len"], h["q_len"], h["db_id"], h["db_id_start"], h["e_acc"], h["e_hyb"],
+                    h["e_tot"], tuple(map(tuple, h["bp"].tolist()))) for h in gap]
+            assert sorted(per_query(hits, bp, q)) == sorted(ref), q
+    finally:
+        qb.close()
+        db.close()
+        odb.close()
+
+
 @pytest.mark.parametrize("tag", ["mix", "quirk"])
 def test_streamed_database_gives_the_same_hits(ctx, golden_dir, tag):
     """a database opened with a residency cap of one page (every search uploads its page) and of
