@@ -1239,6 +1239,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     gs.cap_diag = cap_diag;
     gs.cap_rec = cap_rec;
     gs.bytes_per_thread = gapped_wave_scratch_bytes(cap_diag, cap_rec);
+    if (gs.bytes_per_thread <= kGapWaveLdsBytes && !getenv("PRB_GAPPED_WAVE_HBM")) { // the state fits the LDS of a workgroup
+      gs.base = nullptr;
+      gs.nthreads = (int32_t)std::min<int64_t>(n, 4096);
+      return PRB_OK;
+    }
     int64_t nw = std::min<int64_t>(n, 4096);
     while (nw > 64 && (size_t)nw * gs.bytes_per_thread > ((size_t)4 << 30)) nw /= 2;
     gs.nthreads = (int32_t)nw;

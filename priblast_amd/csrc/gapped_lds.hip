@@ -1096,10 +1096,15 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
   prof.flush(a.tier_id * 2 + (kMode != 0));
 }
 
-// HBM-scratch form: one wavefront per hit, so the plain nesting (hit, direction, anti-diagonal).
-template <int kMode> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs a, GapScratch scratch) {
+// Run-time sized form: one wavefront per hit, so the plain nesting (hit, direction, anti-diagonal).  The state block
+// lies in HBM scratch - or, kInLds, in the workgroup's dynamic LDS when it fits (the first attempt's 512
+// anti-diagonals / 2,048 cells are 43 KB): the same code through the same generic pointers, every access an LDS
+// instead of an HBM round trip.  These are the ~150 longest extensions of 2e7, one wavefront each with the GPU
+// otherwise idle: what counts is the latency of the longest one (2.5 ms from HBM scratch, twice per query).
+template <int kMode, bool kInLds> __global__ __launch_bounds__(64) void k_gapped_wave(GapArgs a, GapScratch scratch) {
+  extern __shared__ __align__(16) uint8_t wave_smem[];
   const int gl = threadIdx.x;
-  uint8_t *mine = scratch.base + (size_t)blockIdx.x * scratch.bytes_per_thread; // one block of scratch per wavefront
+  uint8_t *mine = kInLds ? wave_smem : scratch.base + (size_t)blockIdx.x * scratch.bytes_per_thread; // one block per wavefront
   HbmStore S;
   S.capd = scratch.cap_diag;
   S.capr = scratch.cap_rec;
@@ -1193,9 +1198,15 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, kWaveTier, first_flag, bp_count,
             nullptr, bp_off, bp_out, nullptr, GapResume{nullptr, nullptr, nullptr, 0}, GapResume{nullptr, nullptr, nullptr, 0}};
-  const int blocks = scratch.nthreads; // here: number of wavefronts that own a scratch block
-  if (mode == 0) hipLaunchKernelGGL(k_gapped_wave<0>, dim3(blocks), dim3(64), 0, s, a, scratch);
-  else hipLaunchKernelGGL(k_gapped_wave<2>, dim3(blocks), dim3(64), 0, s, a, scratch);
+  const int blocks = scratch.nthreads; // here: number of wavefronts that own a state block
+  if (scratch.base == nullptr) { // state in LDS
+    const size_t lds = scratch.bytes_per_thread;
+    if (mode == 0) hipLaunchKernelGGL((k_gapped_wave<0, true>), dim3(blocks), dim3(64), lds, s, a, scratch);
+    else hipLaunchKernelGGL((k_gapped_wave<2, true>), dim3(blocks), dim3(64), lds, s, a, scratch);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((k_gapped_wave<0, false>), dim3(blocks), dim3(64), 0, s, a, scratch);
+    else hipLaunchKernelGGL((k_gapped_wave<2, false>), dim3(blocks), dim3(64), 0, s, a, scratch);
+  }
   return hipGetLastError();
 }
 

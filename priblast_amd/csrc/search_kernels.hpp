@@ -172,8 +172,9 @@ hipError_t launch_filter_round(const HitSoA &h, int64_t n, const int64_t *pmax, 
 hipError_t launch_filter_final(const HitSoA &h, int64_t n, const int64_t *pmax, const uint8_t *state, uint8_t *keep,
                                hipStream_t s);
 // ---- gapped ----
+constexpr size_t kGapWaveLdsBytes = 64 * 1024; // a state block up to this size can live in the workgroup's LDS
 struct GapScratch {
-  uint8_t *base;           // one block per wavefront
+  uint8_t *base;           // one block per wavefront; nullptr = in the wavefront's (dynamic) LDS
   size_t bytes_per_thread; // bytes per block
   int32_t cap_rec, cap_diag;
   int32_t nthreads;        // number of wavefronts (= grid size)

@@ -161,7 +161,8 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
-                                 "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_LANE", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1"])
+                                 "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_LANE", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
+                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
     LDS kernel (normally only the extensions that outgrow the smaller tiers) must give the same
@@ -169,10 +170,11 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     cascade with the experimental lane-per-hit kernel in front (PRB_GAPPED_LANE); likewise re-extending the final
     hits (all, or those with more than one traced pair per side) instead of reading their
     base pairs from the trace slots of the extension pass; likewise the general four-key sort
-    instead of the one-key sort + tie pass; likewise the seeds written as a list and extended in a second pass
+    instead of the one-key sort + tie pass; likewise the wavefront-per-hit kernel with its state in HBM scratch instead
+    of LDS (what it uses when the state outgrows 64 KB); likewise the seeds written as a list and extended in a second pass
     (rows by database position, or in the reference's suffix-array order) instead of the one-pass form."""
     from priblast_amd import capi
-    env, _, value = env.partition("=")
+    settings = [e.partition("=")[::2] for e in env.split(",")]
     for tag in ("c1", "mix", "quirk"):
         names, seqs = refdump.read_fasta(os.path.join(GOLDEN, f"{tag}_q.fa"))
         db = capi.Db(ctx, os.path.join(golden_dir, f"{tag}db"))
@@ -180,14 +182,17 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
         qb.accessibility(db.W, db.delta)
         try:
             for page in range(db.npages):
-                monkeypatch.delenv(env, raising=False)
+                for name, _ in settings:
+                    monkeypatch.delenv(name, raising=False)
                 h1, bp1, c1 = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
-                monkeypatch.setenv(env, value or "1")
+                for name, value in settings:
+                    monkeypatch.setenv(name, value or "1")
                 h2, bp2, c2 = capi.search_page(ctx, qb, db, page, capi.default_opts(output_style=1))
                 assert c1 == c2
                 assert np.array_equal(h1, h2) and np.array_equal(bp1, bp2)
         finally:
-            monkeypatch.delenv(env, raising=False)
+            for name, _ in settings:
+                monkeypatch.delenv(name, raising=False)
             qb.close()
             db.close()
 
