@@ -63,7 +63,7 @@ struct SearchWs {
     }
     return PRB_OK;
   }
-  PinnedBuf pinned, cand_pinned, pin_hits[2], pin_bp[2];
+  PinnedBuf pinned, cand_pinned, tb_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
@@ -78,6 +78,7 @@ struct SearchWs {
     }
     pinned.release();
     cand_pinned.release();
+    tb_pinned.release();
     for (int i = 0; i < 2; i++) {
       pin_hits[i].release();
       pin_bp[i].release();
@@ -1411,25 +1412,30 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       (rc = w.tierFin.ensure((size_t)nfin)) || (rc = w.ntraceFin.ensure((size_t)nfin * 4)))
     return rc;
   {
-    std::vector<uint32_t> pre((size_t)nfin); // index of each final hit's pre-gapped state in U
-    PRB_HIP(hipMemcpyAsync(pre.data(), w.subset.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // host copies of four per-hit arrays + the offsets, in one page-locked block that lives with the workspace (fresh
+    // vectors of 3 MB each were an mmap, ~750 page faults and a munmap apiece, per sub-batch)
+    const size_t NF = (size_t)nfin;
+    if ((rc = w.tb_pinned.ensure(NF * 4 * 3 + NF + 16 + (NF + 1) * 8))) return rc;
+    int64_t *off = static_cast<int64_t *>(w.tb_pinned.p);
+    uint32_t *pre = reinterpret_cast<uint32_t *>(off + NF + 1); // index of each final hit's pre-gapped state in U
+    int32_t *cnt = reinterpret_cast<int32_t *>(pre + NF);
+    uint32_t *ntr = reinterpret_cast<uint32_t *>(cnt + NF);
+    uint8_t *tier_fin = reinterpret_cast<uint8_t *>(ntr + NF);
+    PRB_HIP(hipMemcpyAsync(pre, w.subset.p, NF * 4, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(launch_bp_count(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.ntrace.as<int32_t>(),
                             w.bpCount.as<int32_t>(), ctx->stream));
-    std::vector<int32_t> cnt((size_t)nfin);
-    PRB_HIP(hipMemcpyAsync(cnt.data(), w.bpCount.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipMemcpyAsync(cnt, w.bpCount.p, NF * 4, hipMemcpyDeviceToHost, ctx->stream));
     // which kernel of the cascade completed each final hit, and its chain lengths
-    std::vector<uint8_t> tier_fin((size_t)nfin);
-    std::vector<uint32_t> ntr((size_t)nfin);
     PRB_HIP(launch_gather_u8(w.tierOf.as<uint8_t>(), w.subset.as<uint32_t>(), w.tierFin.as<uint8_t>(), nfin, ctx->stream));
     PRB_HIP(launch_gather_u32(w.ntrace.as<uint32_t>(), w.subset.as<uint32_t>(), w.ntraceFin.as<uint32_t>(), nfin, ctx->stream));
-    PRB_HIP(hipMemcpyAsync(tier_fin.data(), w.tierFin.p, (size_t)nfin, hipMemcpyDeviceToHost, ctx->stream));
-    PRB_HIP(hipMemcpyAsync(ntr.data(), w.ntraceFin.p, (size_t)nfin * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipMemcpyAsync(tier_fin, w.tierFin.p, NF, hipMemcpyDeviceToHost, ctx->stream));
+    PRB_HIP(hipMemcpyAsync(ntr, w.ntraceFin.p, NF * 4, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> off((size_t)nfin + 1, 0);
+    off[0] = 0;
     for (int64_t i = 0; i < nfin; i++) off[i + 1] = off[i] + cnt[i];
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
-    PRB_HIP(hipMemcpyAsync(w.bpOff.p, off.data(), (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    PRB_HIP(hipMemcpyAsync(w.bpOff.p, off, (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.first.as<uint8_t>(), w.ntrace.as<int32_t>(),
                              w.tierOf.as<uint8_t>(), w.trace.as<uint16_t>(), w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(),
                              ctx->stream));
