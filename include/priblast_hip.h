@@ -73,6 +73,11 @@ typedef struct prb_hit {
 
 const char *prb_last_error(void);
 const char *prb_version(void);
+/* CPUs the process may keep busy (hardware threads, affinity mask, cgroup CPU quota) and the size the library gives
+ * each of its pools of host threads by default (suffix arrays + seed DFS; result lines): half of that, at most 32;
+ * PRB_HOST_THREADS overrides.  The reference sizes its one pool with OMP_NUM_THREADS (main.cpp / `-a`). */
+int prb_cpu_budget(void);
+int prb_host_threads_default(void);
 void prb_ris_opts_default(prb_ris_opts *o);
 
 /* ---- context ---- */

@@ -44,6 +44,8 @@ assert HIT_DTYPE.itemsize == ctypes.sizeof(Hit)
 SYMBOLS = {
     "prb_last_error": (ctypes.c_char_p, []),
     "prb_version": (ctypes.c_char_p, []),
+    "prb_cpu_budget": (ctypes.c_int, []),
+    "prb_host_threads_default": (ctypes.c_int, []),
     "prb_ris_opts_default": (None, [P(RisOpts)]),
     "prb_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, P(ctypes.c_void_p)]),
     "prb_ctx_destroy": (None, [ctypes.c_void_p]),

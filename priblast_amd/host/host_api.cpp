@@ -1,5 +1,6 @@
-// C ABI, host-only entry points (stage 2 of the seam: encode + suffix array).
+// C ABI, host-only entry points (stage 2 of the seam: encode + suffix array; the CPU budget of the host thread pools).
 #include "../../include/priblast_hip.h"
+#include "cpu_budget.hpp"
 #include "encoder.hpp"
 #include "suffix_array.hpp"
 
@@ -16,5 +17,8 @@ int prb_suffix_array(const uint8_t *text, int32_t n, int32_t *sa) {
   prb::suffix_array(text, n, sa);
   return PRB_OK;
 }
+
+int prb_cpu_budget(void) { return prb::cpu_budget(); }
+int prb_host_threads_default(void) { return prb::default_host_threads(); }
 
 } // extern "C"

@@ -31,6 +31,17 @@ def test_library_exports_every_declared_symbol(lib):
     assert b"gfx950" in lib.prb_version()
 
 
+def test_host_thread_pools_respect_the_cpu_quota(lib):
+    """The pools of host threads are sized from what the process may keep busy - affinity mask and cgroup CPU quota
+    (cpu.max) - not from the hardware threads it can see: on the one-GPU box that is 16 of 256, and 32-thread pools got
+    every thread of the process parked for the rest of each 100 ms period, the one feeding the GPU included."""
+    import bench
+    budget = lib.prb_cpu_budget()
+    assert budget == bench.host_cores()
+    assert 1 <= budget <= (os.cpu_count() or 1)
+    assert lib.prb_host_threads_default() == max(1, min(32, budget // 2))
+
+
 def test_encoder_and_suffix_array_match_reference(lib):
     names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "c1_q.fa"))
     for s, (enc, sa) in zip(seqs, refdump.read_sa(os.path.join(GOLDEN, "c1_q.sa"))):
