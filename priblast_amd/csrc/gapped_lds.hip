@@ -39,11 +39,13 @@ namespace prb {
 // Developer-only cycle breakdown of the gapped kernel (make PROF=1 builds libpriblast_hip_prof.so;
 // tools/gapped_profile.py reads it).  Not part of the product build.
 #ifdef PRB_GAP_PROFILE
-__device__ unsigned long long g_gap_prof[10 * 16]; // [tier * 2 + (mode != 0)][region]
+constexpr int kProfSlots = 24;
+__device__ unsigned long long g_gap_prof[10 * kProfSlots]; // [tier * 2 + (mode != 0)][region]
 struct GapProf {
-  unsigned long long last, acc[16];
+  unsigned long long last, acc[kProfSlots];
+  int cells_now = 0, cells_prev = 0; // filled cells of this group's anti-diagonal (this step / the step before)
   __device__ __forceinline__ void start() {
-    for (int i = 0; i < 16; i++) acc[i] = 0;
+    for (int i = 0; i < kProfSlots; i++) acc[i] = 0;
     last = __builtin_amdgcn_s_memtime();
   }
   __device__ __forceinline__ void mark(int r) {
@@ -54,7 +56,7 @@ struct GapProf {
   __device__ __forceinline__ void count(int r) { acc[r] += 1; }
   __device__ __forceinline__ void flush(int kind) {
     if ((threadIdx.x & 63) == 0)
-      for (int i = 0; i < 16; i++) atomicAdd(&g_gap_prof[kind * 16 + i], acc[i]);
+      for (int i = 0; i < kProfSlots; i++) atomicAdd(&g_gap_prof[kind * kProfSlots + i], acc[i]);
   }
 };
 #define GP_MARK(r) prof.mark(r)
@@ -77,24 +79,28 @@ struct Tier0 { // 1.26 KB per hit, 4 workgroups of 256 threads (32 hits) per CU 
   static constexpr int kG = 8, kCapD = 30, kCapR = 48, kGroups = 32, kWavesPerSimd = 4, kWgPerCu = 4;
   static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by the next tier
   static constexpr bool kResumes = false;
+  static constexpr bool kPairSteps = true; // two anti-diagonals per step where that is safe (dir_step_pair)
 };
 struct Tier1 { // 1.65 KB per hit, 3 workgroups of 256 threads (32 hits) per CU: the hits a little too long for tier 0
   static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
   static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 0, leaves its own
   using From = Tier0;
   using FromRec = Rec32;
+  static constexpr bool kPairSteps = false;
 };
 struct Tier2 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
   static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
   static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 1, leaves its own
   using From = Tier1;
   using FromRec = Rec32;
+  static constexpr bool kPairSteps = false;
 };
 struct Tier3 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
   static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
   static constexpr bool kResumable = false, kResumes = true; // continues the state dumps of tier 2
   using From = Tier2;
   using FromRec = Rec32;
+  static constexpr bool kPairSteps = false;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -695,6 +701,9 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
       }
     }
     GP_MARK(3);
+#ifdef PRB_GAP_PROFILE
+    prof.cells_now = kChunks <= 4 ? __popc((uint32_t)cells) : __popcll((unsigned long long)cells);
+#endif
     while (cells) { // filled cells of the anti-diagonal, ascending i, two at a time where there are two
       const cells_t rest = cells & (cells - 1);
       const bool two = rest != 0 && d.nrec + 2 <= S.cap_r();
@@ -760,6 +769,254 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
   if (d.length - (d.min_ci + d.min_cj) >= drop) return true;
   if (!q_open && !d_open) return true;
   return false;
+}
+
+// dir_step for eight-lane groups with at most 32 cells per anti-diagonal, TWO anti-diagonals per call where that
+// changes nothing.  The eight groups of a wavefront run their fill loops in lockstep, so a step costs what its busiest
+// group needs - 1.31 iterations per anti-diagonal where a group has 0.68 cells (PROF build, configs[2] shape).  Cells
+// of anti-diagonal L + 1 never take a cell of L as predecessor (ri < ci and rj < cj with ri + rj = L, ci + cj = L + 1
+// is impossible), and their helix check reads the types of L - 1: the two anti-diagonals only meet in the cell list
+// and in the running minimum, both of which take A's cells before B's.  One fill loop over both: 2.10 iterations
+// instead of 2.62, one pass through the prologue and the loop top instead of two.
+// B is taken along only when A cannot be the last anti-diagonal (no improvement for `drop` lengths / both strands at
+// their ends), the state has room for both in full, and B's accessibility sums are staged; else the call is dir_step.
+// The list as B's cells see it: live candidates [loB, dstartA) - A's cells lie behind and never qualify -, and the
+// default predecessor of a cell without candidates is entry loB, which is A's first cell when everything older has
+// been pruned (its type is known from the check, the record itself may not be written yet).
+template <class Store>
+__device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBases &sb, const ExtOpts &o, const HitCtx &c, int flag,
+                                              const Store &S, int gl, int gbase, DirState &d, GapProf &prof) {
+  constexpr int G = 8;
+  using R = typename Store::R;
+  static_assert(Store::kCapD <= 32, "a 32-bit mask of cells per anti-diagonal");
+  constexpr int kChunks = (Store::kCapD + G - 1) / G;
+  const int delta = o.delta, drop = o.drop_w_gap, min_helix = o.min_helix;
+  const bool mid = d.resume_i0 != 0; // continuing an anti-diagonal that could not be finished
+  if (!mid) {
+    if (d.length >= S.cap_d()) {
+      d.overflow = true;
+      return true;
+    }
+    d.length++;
+  }
+  const int LA = d.length;
+  const bool openA = LA < d.tq0 || LA < d.td0;
+  const int curA = LA - 3 * ((LA * 171) >> 9), d2A = curA == 2 ? 0 : curA + 1; // LA mod 3, (LA - 2) mod 3
+  if (!mid) {
+    if (LA > d.staged) stage_acc_regs<G, true>(sb, c, flag, delta, S, gl, gbase, d, LA);
+    GP_MARK(1);
+    GP_COUNT(10);
+    uint64_t *row = reinterpret_cast<uint64_t *>(&S.ptab(curA, 0));
+    for (int t = gl; t < S.ptab_len() / 8; t += G) row[t] = 0;
+    group_sync<true>();
+    if (LA - 2 > drop) {
+      while (d.lo < d.nrec) {
+        const auto v = S.info(d.lo);
+        if (LA - R::i(v) - R::j(v) - 2 > drop) d.lo++;
+        else break;
+      }
+    }
+  }
+  GP_MARK(2);
+  const int dstartA = mid ? d.resume_dstart : d.nrec, loA = d.lo;
+  const int i_firstA = LA - d.td0 + 1 > 1 ? LA - d.td0 + 1 : 1;
+  const int i_loA = mid ? d.resume_i0 : i_firstA;
+  const int i_hiA = (LA < d.tq0 ? LA : d.tq0) - 1;
+  d.resume_i0 = 0;
+
+  // pair type of the cell (i, j) whose bases pair, as dir_step's cell_type has it
+  auto pair_type = [&](int i, int j) -> int {
+    const unsigned x0 = (unsigned)S.qb(i) * 5 + S.db(j);
+    int t = (int)((sc.bp_rows >> ((x0 * 3 - 15) & 63)) & 7);
+    if (flag == 1) t = ((t - 1) ^ 1) + 1;
+    return t;
+  };
+  // CheckHelixLength + GetBPType for cell (i, L - i), see dir_step
+  auto cell_ok = [&](int L, int d2row, int i, int i_hi) -> bool {
+    if (i > i_hi) return false;
+    const int j = L - i;
+    const unsigned q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
+    const int pt = S.ptab(d2row, i - 1);
+    const unsigned x0 = q0 * 5 + d0, x1 = q1 * 5 + d1, x2 = q2 * 5 + d2b;
+    const unsigned p0 = (sc.pair_mask >> x0) & 1, w0 = (sc.wobble_mask >> x0) & 1;
+    unsigned ahead = 1;
+    if (min_helix >= 2) ahead = ((sc.pair_mask >> x1) & 1) & ~(w0 & (sc.wobble_mask >> x1));
+    if (min_helix >= 3) ahead &= sc.pair_mask >> x2;
+    for (int x = 3; x <= min_helix - 1; x++) ahead &= sc.pair_mask >> ((unsigned)S.qb(i + x) * 5 + S.db(j + x));
+    const unsigned need = (unsigned)(pt == 0) | (w0 & (unsigned)wobble(pt));
+    return (p0 & (ahead | ~need) & 1) != 0;
+  };
+  auto check = [&](int L, int d2row, int i_lo, int i_hi) -> uint32_t {
+    uint32_t cells = 0;
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ch++) {
+      const int i0 = i_lo + ch * G;
+      if (i0 <= i_hi) {
+        cells |= (uint32_t)((__ballot(cell_ok(L, d2row, i0 + gl, i_hi)) >> gbase) & 0xFF) << (8 * ch);
+        GP_COUNT(11);
+      }
+    }
+    return cells;
+  };
+  const uint32_t cellsA = check(LA, d2A, i_loA, i_hiA);
+  const int nA = __popc(cellsA);
+
+  // ---- anti-diagonal B = LA + 1 in the same fill loop? ----
+  const int LB = LA + 1, d2B = curA == 0 ? 2 : curA - 1; // (LB - 2) mod 3; LB mod 3 = (LA - 2) mod 3 = d2A
+  uint32_t cellsB = 0;
+  int loB = loA;
+  bool paired = false;
+  if (!mid && openA && LA - (d.min_ci + d.min_cj) < drop && LA < S.cap_d() && LB <= d.staged) {
+    if (LB - 2 > drop) {
+      while (loB < dstartA) {
+        const auto v = S.info(loB);
+        if (LB - R::i(v) - R::j(v) - 2 > drop) loB++;
+        else break;
+      }
+    }
+    const int i_hiB = (LB < d.tq0 ? LB : d.tq0) - 1;
+    cellsB = check(LB, d2B, LB - d.td0 + 1 > 1 ? LB - d.td0 + 1 : 1, i_hiB);
+    if (d.nrec + nA + __popc(cellsB) <= S.cap_r()) {
+      paired = true;
+      // B's types go to the row of LA - 2: the check of A has read it - and will not read it again, which it would if
+      // A ran out of cells half way and the next tier took over (hence only now that there is room for A and B in full)
+      uint64_t *row = reinterpret_cast<uint64_t *>(&S.ptab(d2A, 0));
+      for (int t = gl; t < S.ptab_len() / 8; t += G) row[t] = 0;
+      group_sync<true>();
+      GP_COUNT(10);
+    } else {
+      cellsB = 0;
+    }
+  }
+  int typeA0 = 0; // Stem::type of A's first cell as its record will hold it (0: A has no cell)
+  if (paired && nA != 0) {
+    const int iA0 = i_loA + __builtin_ctz(cellsA);
+    typeA0 = rtype_of(pair_type(iA0, LA - iA0));
+  }
+#ifdef PRB_GAP_PROFILE
+  prof.cells_now = nA + __popc(cellsB);
+#endif
+  GP_MARK(3);
+
+  // one filled cell, or two at once on four lanes each (dir_step's fill_cell; a cell brings its anti-diagonal along)
+  auto fill_cell = [&](int ci, bool isB, bool two) -> int {
+    GP_COUNT(12);
+    const bool pair_mode = two, hi = pair_mode && gl >= G / 2;
+    const int sub = pair_mode ? (gl & (G / 2 - 1)) : gl, stride = pair_mode ? G / 2 : G;
+    const int L = LA + (isB ? 1 : 0), cur = isB ? (curA == 2 ? 0 : curA + 1) : curA, lo = isB ? loB : loA;
+    const int cj = L - ci;
+    const int ctype = pair_type(ci, cj);
+    const int nq = S.qb(ci - 1), nd = S.db(cj - 1);
+    double bte = 1000000.0; // INF
+    int bkp = lo << 3;
+    // (no records fetched ahead at the start of the step, nor the cell's own values ahead of the scan, as dir_step does:
+    // the registers they occupy cost more here than the LDS latency they hide)
+    typename R::word vn = 0;
+    double hn = 0;
+    if (lo + sub < dstartA) {
+      vn = S.info(lo + sub);
+      hn = S.hyb(lo + sub);
+    }
+    for (int k0 = lo; k0 < dstartA; k0 += stride) {
+      GP_COUNT(13);
+      const int k = k0 + sub;
+      const auto v = vn;
+      const double hk = hn;
+      if (k + stride < dstartA) {
+        vn = S.info(k + stride);
+        hn = S.hyb(k + stride);
+      }
+      if (k < dstartA) {
+        const int ri = R::i(v), rj = R::j(v);
+        if (ri < ci && rj < cj) {
+          const int rq = R::qa(v), rd = R::da(v);
+          const bool f0 = flag == 0;
+          const int rt = R::type(v);
+          double te = loop_energy_abcd(sc, f0 ? ctype : rt, f0 ? rt : ctype, ci - ri - 1, cj - rj - 1, f0 ? nq : rq, f0 ? nd : rd,
+                                       f0 ? rq : nq, f0 ? rd : nd);
+          te += hk;
+          if (te < bte) {
+            bte = te;
+            bkp = (k << 3) | R::type(v);
+          }
+        }
+      }
+    }
+    GP_MARK(4);
+    group_min_halves(bte, bkp, pair_mode);
+    GP_MARK(5);
+    if (d.nrec >= S.cap_r()) return -1;
+    int bk = bkp >> 3, ptype = bkp & 7;
+    // empty window - for a cell of B the list ends behind A's cells -: the reference reads stem_candidate[0] of an empty list
+    const bool a_first = isB && typeA0 != 0 && lo >= dstartA; // the default entry is A's first cell
+    if (lo >= dstartA && !a_first) bk = 0;
+    if (ptype == 0) ptype = a_first ? typeA0 : R::type(S.info(bk)); // no candidate qualified: the type of the default entry
+    const int rec = d.nrec + (hi ? 1 : 0);
+    if (sub == 0) {
+      S.hyb(rec) = bte;
+      S.info(rec) = R::pack(ci, cj, bk, rtype_of(ctype), S.qb(ci + 1), S.db(cj + 1));
+      S.ptab(cur, ci) = (uint8_t)ptype;
+    }
+    const double ie = S.eq(ci - 1) + S.ed(cj - 1) + bte;
+    // the first cell (lanes 0-3), then the second (lanes 4-7): each half gets the other's values from its mirror lane
+    const double ie_o = dpp_f64<0x141>(ie);
+    const int ci_o = dpp_i32<0x141>(ci), cj_o = dpp_i32<0x141>(cj);
+    const double ie_a = hi ? ie_o : ie, ie_b = hi ? ie : ie_o;
+    const int ci_a = hi ? ci_o : ci, ci_b = hi ? ci : ci_o, cj_a = hi ? cj_o : cj, cj_b = hi ? cj : cj_o;
+    if (ie_a < d.min_e) {
+      d.min_e = ie_a;
+      d.best = d.nrec;
+      d.min_ci = ci_a;
+      d.min_cj = cj_a;
+    }
+    if (pair_mode && ie_b < d.min_e) {
+      d.min_e = ie_b;
+      d.best = d.nrec + 1;
+      d.min_ci = ci_b;
+      d.min_cj = cj_b;
+    }
+    d.nrec += pair_mode ? 2 : 1;
+    GP_MARK(6);
+    return ptype;
+  };
+
+  unsigned long long cells = (unsigned long long)cellsA | ((unsigned long long)cellsB << 32);
+  while (cells) { // filled cells of A, then of B, ascending i, two at a time where there are two
+    const unsigned long long rest = cells & (cells - 1);
+    const bool two = rest != 0 && d.nrec + 2 <= S.cap_r();
+    const int b0 = __builtin_ctzll(cells);
+    if (Store::kResumable && d.nrec >= S.cap_r()) { // out of cells (never with B along): stop in front of this one
+      d.overflow = true;
+      d.resume_i0 = i_loA + b0;
+      d.resume_dstart = dstartA;
+      break;
+    }
+    int b = b0;
+    if (two) {
+      if (gl >= G / 2) b = __builtin_ctzll(rest);
+      cells = rest & (rest - 1);
+    } else {
+      cells = rest;
+    }
+    const bool isB = b >= 32;
+    const int i_loB = LA + 2 - d.td0 > 1 ? LA + 2 - d.td0 : 1; // (first cell of anti-diagonal LA + 1)
+    const int ptype = fill_cell((isB ? i_loB : i_loA) + (b & 31), isB, two);
+    if (ptype < 0) {
+      d.overflow = true;
+      break;
+    }
+  }
+  group_sync<true>();
+  GP_MARK(3);
+  if (d.overflow) return true;
+  if (paired) {
+    d.length = LA + 1;
+    d.lo = loB;
+    if (LB - (d.min_ci + d.min_cj) >= drop) return true;
+    return !(LB < d.tq0 || LB < d.td0);
+  }
+  if (LA - (d.min_ci + d.min_cj) >= drop) return true;
+  return !openA;
 }
 
 // The hit after the direction (:300-318): grown by the cell of the minimum, if there is one.
@@ -1024,8 +1281,9 @@ __global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const ui
 // longer extension just misses a boundary or two instead of holding up the whole wavefront
 // (PROF build: with hit-by-hit lockstep 36 % of the wave time was spent waiting for the longest
 // extension; with free-running groups 40 % on each other's divergent transitions).
-template <int kMode, class T, class Rec>
+template <int kMode, class T, class Rec, bool kPair>
 __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_lds(GapArgs a) {
+  static_assert(!kPair || (T::kPairSteps && T::kG == 8), "dir_step_pair");
   __shared__ LdsState<T, Rec> lds[T::kGroups];
   constexpr int G = T::kG;
   const int gl = threadIdx.x & (G - 1);
@@ -1038,7 +1296,8 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
   int64_t w = (int64_t)blockIdx.x * T::kGroups + gid;
   enum { kLoad, kInit, kRun, kFinished, kDone };
   int phase = w < a.n ? kLoad : kDone, flag = 0;
-  const int period = a.o.drop_w_gap > 1 ? a.o.drop_w_gap : 1;
+  // (with two anti-diagonals per step a direction without improvement takes (drop + 1) / 2 steps)
+  const int period = kPair ? (a.o.drop_w_gap > 1 ? (a.o.drop_w_gap + 1) / 2 : 1) : (a.o.drop_w_gap > 1 ? a.o.drop_w_gap : 1);
   int tick = 0; // iterations since the last boundary
   HitCtx c;
   DirState d;
@@ -1090,7 +1349,40 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
       }
     }
     GP_MARK(15);
-    if (phase == kRun && dir_step<G, true>(a.sc, sb, a.o, c, flag, S, gl, gbase, d, prof)) phase = kFinished;
+#ifdef PRB_GAP_PROFILE
+    prof.cells_now = 0;
+#endif
+    if constexpr (kPair) {
+      if (phase == kRun && dir_step_pair(a.sc, sb, a.o, c, flag, S, gl, gbase, d, prof)) phase = kFinished;
+    } else {
+      if (phase == kRun && dir_step<G, true>(a.sc, sb, a.o, c, flag, S, gl, gbase, d, prof)) phase = kFinished;
+    }
+#ifdef PRB_GAP_PROFILE
+    if constexpr (G == 8) { // wave-level fill iterations: as they are (two cells per iteration), and if two anti-diagonals shared a loop
+      auto wave_max = [](int v) {
+        for (int m = 32; m >= 8; m >>= 1) {
+          const int o = __shfl_xor(v, m);
+          v = o > v ? o : v;
+        }
+        return v;
+      };
+      const int cn = prof.cells_now;
+      prof.acc[16] += (unsigned long long)wave_max((cn + 1) / 2);
+      prof.acc[17] += (unsigned long long)wave_max(cn);
+      auto wave_sum = [](int v) {
+        for (int m = 32; m >= 8; m >>= 1) v += __shfl_xor(v, m);
+        return v;
+      };
+      prof.acc[18] += (unsigned long long)wave_sum(cn);
+      if (tick & 1) {
+        prof.acc[19] += (unsigned long long)wave_max((cn + prof.cells_prev + 1) / 2);
+        prof.acc[20] += 1;
+      } else {
+        prof.cells_prev = cn;
+      }
+      prof.acc[21] += 1;
+    }
+#endif
     tick = tick + 1 == period ? 0 : tick + 1;
   }
   prof.flush(a.tier_id * 2 + (kMode != 0));
@@ -1148,9 +1440,9 @@ template <int kMode, bool kInLds> __global__ __launch_bounds__(64) void k_gapped
 #ifdef PRB_GAP_PROFILE
 extern "C" int prb_debug_gap_profile(unsigned long long *out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gap_prof), sizeof(unsigned long long) * 160) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gap_prof), sizeof(unsigned long long) * 10 * kProfSlots) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[160] = {};
+    unsigned long long z[10 * kProfSlots] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_gap_prof), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
@@ -1171,8 +1463,16 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
   const int64_t want = (a.n + T::kGroups - 1) / T::kGroups;
   const dim3 grid((unsigned)std::min<int64_t>(want, 256 * T::kWgPerCu)), blk(T::kG * T::kGroups);
   if (hipError_t e = hipMemsetAsync(a.next_work, 0, sizeof(unsigned long long), s); e != hipSuccess) return e;
-  if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec>), grid, blk, 0, s, a);
-  else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec>), grid, blk, 0, s, a);
+  if constexpr (T::kPairSteps) {
+    static const bool pair = !(getenv("PRB_GAPPED_PAIR") && atoi(getenv("PRB_GAPPED_PAIR")) == 0);
+    if (pair) {
+      if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec, true>), grid, blk, 0, s, a);
+      else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec, true>), grid, blk, 0, s, a);
+      return hipGetLastError();
+    }
+  }
+  if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec, false>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec, false>), grid, blk, 0, s, a);
   return hipGetLastError();
 }
 } // namespace

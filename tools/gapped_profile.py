@@ -35,12 +35,12 @@ def main():
     qb = capi.QBatch(ctx, qs, db.repeat_flag)
     qb.accessibility(db.W, db.delta)
     L = capi.lib()
-    buf = (ctypes.c_ulonglong * 160)()
+    buf = (ctypes.c_ulonglong * 240)()
     L.prb_debug_gap_profile(buf, 1)
     ctx.reset_timers()
     hits, bp, counts = capi.search_page(ctx, qb, db, 0, capi.default_opts(), 3)
     L.prb_debug_gap_profile(buf, 1)
-    allv = np.array(buf[:], dtype=np.float64).reshape(10, 16)
+    allv = np.array(buf[:], dtype=np.float64).reshape(10, 24)
     print(f"hits: seed {counts[0]}, post-ungapped {counts[1]}, final {counts[2]}")
     for s in ("gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow"):
         print(f"  {s}: {ctx.stage_ms(s)[0]:.1f} ms")
@@ -58,6 +58,11 @@ def main():
         print(f"{name}: {cyc / total * 100:.1f} % of all gapped wave-cycles")
         for i in list(range(10)) + [14, 15]:
             print(f"  {REGIONS[i]:24s} {v[i] / cyc * 100:6.2f} %")
+        if v[21]:
+            print(f"  wave-level, per lockstep step ({v[21]:.0f} steps): fill iterations {v[16] / v[21]:.3f} (two cells each), "
+                  f"busiest group's cells {v[17] / v[21]:.3f}, cells per group {v[18] / v[21] / 8:.3f}; "
+                  f"if two anti-diagonals shared a fill loop: {v[19] / max(v[20], 1):.3f} iterations per pair of steps "
+                  f"(now {2 * v[16] / v[21]:.3f})")
         print("  wave-level counts: " + ", ".join(f"{REGIONS[i]} {v[i]:.3g}" for i in range(10, 14)))
 
 
