@@ -831,13 +831,9 @@ __device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBa
     if (flag == 1) t = ((t - 1) ^ 1) + 1;
     return t;
   };
-  // CheckHelixLength + GetBPType for cell (i, L - i), see dir_step
-  auto cell_ok = [&](int L, int d2row, int i, int i_hi) -> bool {
-    if (i > i_hi) return false;
-    const int j = L - i;
-    const unsigned q0 = S.qb(i), d0 = S.db(j), q1 = S.qb(i + 1), d1 = S.db(j + 1), q2 = S.qb(i + 2), d2b = S.db(j + 2);
-    const int pt = S.ptab(d2row, i - 1);
-    const unsigned x0 = q0 * 5 + d0, x1 = q1 * 5 + d1, x2 = q2 * 5 + d2b;
+  // CheckHelixLength + GetBPType (see dir_step's cell_type) for cell (i, j): x0, x1, x2 = 5 * query base + database base
+  // of the cell and of the two positions ahead of it on its diagonal, pt = Cell::type of its diagonal predecessor
+  auto helix_ok = [&](unsigned x0, unsigned x1, unsigned x2, int pt, int i, int j) -> bool {
     const unsigned p0 = (sc.pair_mask >> x0) & 1, w0 = (sc.wobble_mask >> x0) & 1;
     unsigned ahead = 1;
     if (min_helix >= 2) ahead = ((sc.pair_mask >> x1) & 1) & ~(w0 & (sc.wobble_mask >> x1));
@@ -846,27 +842,14 @@ __device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBa
     const unsigned need = (unsigned)(pt == 0) | (w0 & (unsigned)wobble(pt));
     return (p0 & (ahead | ~need) & 1) != 0;
   };
-  auto check = [&](int L, int d2row, int i_lo, int i_hi) -> uint32_t {
-    uint32_t cells = 0;
-#pragma unroll
-    for (int ch = 0; ch < kChunks; ch++) {
-      const int i0 = i_lo + ch * G;
-      if (i0 <= i_hi) {
-        cells |= (uint32_t)((__ballot(cell_ok(L, d2row, i0 + gl, i_hi)) >> gbase) & 0xFF) << (8 * ch);
-        GP_COUNT(11);
-      }
-    }
-    return cells;
-  };
-  const uint32_t cellsA = check(LA, d2A, i_loA, i_hiA);
-  const int nA = __popc(cellsA);
 
-  // ---- anti-diagonal B = LA + 1 in the same fill loop? ----
-  const int LB = LA + 1, d2B = curA == 0 ? 2 : curA - 1; // (LB - 2) mod 3; LB mod 3 = (LA - 2) mod 3 = d2A
-  uint32_t cellsB = 0;
+  // ---- anti-diagonal B = LA + 1 in the same fill loop?  (LB mod 3 = (LA - 2) mod 3 = d2A; (LB - 2) mod 3 = d2B) ----
+  const int LB = LA + 1, d2B = curA == 0 ? 2 : curA - 1;
+  const bool try_pair = !mid && openA && LA - (d.min_ci + d.min_cj) < drop && LA < S.cap_d() && LB <= d.staged;
+  uint32_t cellsA = 0, cellsB = 0; // bit b: cell i = i_loA + b (both)
   int loB = loA;
   bool paired = false;
-  if (!mid && openA && LA - (d.min_ci + d.min_cj) < drop && LA < S.cap_d() && LB <= d.staged) {
+  if (try_pair) {
     if (LB - 2 > drop) {
       while (loB < dstartA) {
         const auto v = S.info(loB);
@@ -874,9 +857,24 @@ __device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBa
         else break;
       }
     }
-    const int i_hiB = (LB < d.tq0 ? LB : d.tq0) - 1;
-    cellsB = check(LB, d2B, LB - d.td0 + 1 > 1 ? LB - d.td0 + 1 : 1, i_hiB);
-    if (d.nrec + nA + __popc(cellsB) <= S.cap_r()) {
+    // both checks in one pass: cell i of A is (i, LA - i), of B (i, LA + 1 - i) - the same three query bases, four
+    // database bases instead of twice three
+    const int i_loB = LB - d.td0 + 1 > 1 ? LB - d.td0 + 1 : 1, i_hiB = (LB < d.tq0 ? LB : d.tq0) - 1; // (i_hiB >= i_hiA)
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ch++) {
+      const int i0 = i_loA + ch * G;
+      if (i0 <= i_hiB) {
+        const int i = i0 + gl, j = LA - i, jc = j < 0 ? 0 : j; // (a lane beyond both ranges computes on whatever it reads)
+        const unsigned q0 = (unsigned)S.qb(i) * 5, q1 = (unsigned)S.qb(i + 1) * 5, q2 = (unsigned)S.qb(i + 2) * 5;
+        const unsigned d0 = S.db(jc), d1 = S.db(jc + 1), d2b = S.db(jc + 2), d3 = S.db(jc + 3);
+        const bool okA = i <= i_hiA && helix_ok(q0 + d0, q1 + d1, q2 + d2b, S.ptab(d2A, i - 1), i, j);
+        const bool okB = i >= i_loB && i <= i_hiB && helix_ok(q0 + d1, q1 + d2b, q2 + d3, S.ptab(d2B, i - 1), i, j + 1);
+        cellsA |= (uint32_t)((__ballot(okA) >> gbase) & 0xFF) << (8 * ch);
+        cellsB |= (uint32_t)((__ballot(okB) >> gbase) & 0xFF) << (8 * ch);
+        GP_COUNT(11);
+      }
+    }
+    if (d.nrec + __popc(cellsA) + __popc(cellsB) <= S.cap_r()) {
       paired = true;
       // B's types go to the row of LA - 2: the check of A has read it - and will not read it again, which it would if
       // A ran out of cells half way and the next tier took over (hence only now that there is room for A and B in full)
@@ -887,7 +885,21 @@ __device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBa
     } else {
       cellsB = 0;
     }
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ch++) {
+      const int i0 = i_loA + ch * G;
+      if (i0 <= i_hiA) {
+        const int i = i0 + gl, j = LA - i, jc = j < 0 ? 0 : j;
+        const unsigned x0 = (unsigned)S.qb(i) * 5 + S.db(jc), x1 = (unsigned)S.qb(i + 1) * 5 + S.db(jc + 1),
+                       x2 = (unsigned)S.qb(i + 2) * 5 + S.db(jc + 2);
+        const bool okA = i <= i_hiA && helix_ok(x0, x1, x2, S.ptab(d2A, i - 1), i, j);
+        cellsA |= (uint32_t)((__ballot(okA) >> gbase) & 0xFF) << (8 * ch);
+        GP_COUNT(11);
+      }
+    }
   }
+  const int nA = __popc(cellsA);
   int typeA0 = 0; // Stem::type of A's first cell as its record will hold it (0: A has no cell)
   if (paired && nA != 0) {
     const int iA0 = i_loA + __builtin_ctz(cellsA);
@@ -999,8 +1011,7 @@ __device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBa
       cells = rest;
     }
     const bool isB = b >= 32;
-    const int i_loB = LA + 2 - d.td0 > 1 ? LA + 2 - d.td0 : 1; // (first cell of anti-diagonal LA + 1)
-    const int ptype = fill_cell((isB ? i_loB : i_loA) + (b & 31), isB, two);
+    const int ptype = fill_cell(i_loA + (b & 31), isB, two);
     if (ptype < 0) {
       d.overflow = true;
       break;
