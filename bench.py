@@ -25,7 +25,7 @@ submitted inside the timed region is finished inside it.  Weak scaling: every ra
 writes all lines.
 
 One JSON line is printed by rank 0 (contract in the task description) with
-  roofline     : dominant kernel (k_gapped_lds tier 0) - algorithmic bytes = 600 B per post-ungapped hit
+  roofline     : dominant kernel (k_gapped_lds<0, Tier0, Rec32, true>: tier 0, two anti-diagonals per step) - algorithmic bytes = 600 B per post-ungapped hit
                  (DESIGN.md "Measurement") / device time from HIP events on the
                  library's stream, against the 8 TB/s HBM peak;
   cpu_baseline : the unmodified reference (oracle/_ref/pRIblast.shipped, OpenMP) on the same queries
@@ -444,7 +444,7 @@ def main():
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
             "lane_kernel_hits_per_step": ctx.stage_ms("gapped_lane_hits")[1] // a.steps,
             "host_wall_ms_per_step": {k: round(v / a.steps * 1e3, 1) for k, v in wall.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_gapped_lds<0, Tier0, Rec32>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_gapped_lds<0, Tier0, Rec32, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(gap_units / max(gap_launch, 1)),
                          "launches": gap_launch, "avg_launch_ms": gap_ms / max(gap_launch, 1),
                          "units_per_launch": gap_units / max(gap_launch, 1), "bytes_per_unit": GAPPED_BYTES_PER_HIT,

@@ -14,8 +14,8 @@
 // kept redundantly in every lane.  The reference's growing 100x100 Cell matrix never exists.
 // The groups of a wavefront run all of this in lockstep, so a loop costs what its busiest group
 // needs: the kernels are shaped to keep that maximum small (one loop over the filled cells of an
-// anti-diagonal, two cells at once on half a group each, one instruction stream for both
-// directions) rather than to keep every lane busy.
+// anti-diagonal - of two anti-diagonals in tier 0, dir_step_pair -, two cells at once on half a group each, one
+// instruction stream for both directions) rather than to keep every lane busy.
 //
 // Two forms, a cascade of five kernels (a hit goes on to the next one when it outgrows the state a
 // kernel has room for; the LDS tiers hand their state over, so the next tier continues instead of
@@ -1475,7 +1475,8 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
   const dim3 grid((unsigned)std::min<int64_t>(want, 256 * T::kWgPerCu)), blk(T::kG * T::kGroups);
   if (hipError_t e = hipMemsetAsync(a.next_work, 0, sizeof(unsigned long long), s); e != hipSuccess) return e;
   if constexpr (T::kPairSteps) {
-    static const bool pair = !(getenv("PRB_GAPPED_PAIR") && atoi(getenv("PRB_GAPPED_PAIR")) == 0);
+    const char *pe = getenv("PRB_GAPPED_PAIR"); // (read per launch: the tests switch it inside one process)
+    const bool pair = !(pe && atoi(pe) == 0);
     if (pair) {
       if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec, true>), grid, blk, 0, s, a);
       else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec, true>), grid, blk, 0, s, a);

@@ -162,7 +162,7 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
                                  "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_LANE", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
-                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1"])
+                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
     LDS kernel (normally only the extensions that outgrow the smaller tiers) must give the same
@@ -170,7 +170,8 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     cascade with the experimental lane-per-hit kernel in front (PRB_GAPPED_LANE); likewise re-extending the final
     hits (all, or those with more than one traced pair per side) instead of reading their
     base pairs from the trace slots of the extension pass; likewise the general four-key sort
-    instead of the one-key sort + tie pass; likewise the wavefront-per-hit kernel with its state in HBM scratch instead
+    instead of the one-key sort + tie pass; likewise tier 0 with one anti-diagonal per step instead of two; likewise
+    the wavefront-per-hit kernel with its state in HBM scratch instead
     of LDS (what it uses when the state outgrows 64 KB); likewise the seeds written as a list and extended in a second pass
     (rows by database position, or in the reference's suffix-array order) instead of the one-pass form."""
     from priblast_amd import capi
