@@ -34,6 +34,11 @@ OPTION_SETS = [
     dict(min_helix_length=5, final_threshold=-6.0),
     dict(min_helix_length=2),
     dict(min_helix_length=9, interaction_threshold=-2.0, final_threshold=-4.0, drop_out_w_gap=24),
+    # odd and tiny -x: tier 0 takes two anti-diagonals per step, a direction without improvement (x + 1) / 2 steps
+    dict(drop_out_w_gap=5, final_threshold=-6.0),
+    dict(drop_out_w_gap=7, min_helix_length=4, final_threshold=-5.0),
+    dict(drop_out_w_gap=1, final_threshold=-5.0),
+    dict(drop_out_w_gap=19, drop_out_wo_gap=7),
 ]
 ORACLE_NAMES = dict(max_seed_length="max_seed_length", hybrid_threshold="hybrid_thr", interaction_threshold="interaction_thr",
                     final_threshold="final_thr", drop_out_w_gap="drop_w_gap", drop_out_wo_gap="drop_wo_gap",
