@@ -938,6 +938,13 @@ __device__ __forceinline__ bool dir_step_pair(const SearchConst &sc, const SeqBa
         vn = S.info(k + stride);
         hn = S.hyb(k + stride);
       }
+#ifdef PRB_GAP_PROFILE
+      { // lanes with a candidate / with a qualifying candidate in this round (wave-level)
+        const bool has = k < dstartA, ok = has && R::i(v) < ci && R::j(v) < cj;
+        prof.acc[22] += (unsigned long long)__popcll(__ballot(has));
+        prof.acc[23] += (unsigned long long)__popcll(__ballot(ok));
+      }
+#endif
       if (k < dstartA) {
         const int ri = R::i(v), rj = R::j(v);
         if (ri < ci && rj < cj) {

@@ -63,6 +63,9 @@ def main():
                   f"busiest group's cells {v[17] / v[21]:.3f}, cells per group {v[18] / v[21] / 8:.3f}; "
                   f"if two anti-diagonals shared a fill loop: {v[19] / max(v[20], 1):.3f} iterations per pair of steps "
                   f"(now {2 * v[16] / v[21]:.3f})")
+        if v[22]:
+            print(f"  candidates looked at per scan round (as seen by lane 0's wavefront): {v[22] / max(v[13], 1):.1f} lanes, "
+                  f"of which qualify (ri < ci, rj < cj): {v[23] / v[22] * 100:.1f} %")
         print("  wave-level counts: " + ", ".join(f"{REGIONS[i]} {v[i]:.3g}" for i in range(10, 14)))
 
 
