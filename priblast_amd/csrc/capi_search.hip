@@ -1641,6 +1641,8 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   auto *hs = new prb_hitset();
   hs->device = ctx->device;
   hs->on_device = ctx->keep_device_records && last_stage == 3;
+  hs->d_hits.hint = ctx->keep_hint_hits;
+  hs->d_bp.hint = ctx->keep_hint_bp;
   SearchWs &wsp = ws_of(ctx);
   Drainer drain(&hs->hits, &hs->bp, wsp.pin_hits, wsp.pin_bp);
   hs->drain = &drain;
@@ -1721,6 +1723,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   if (rc != PRB_OK) {
     delete hs;
     return rc;
+  }
+  if (hs->on_device) {
+    ctx->keep_hint_hits = hs->d_hits.used;
+    ctx->keep_hint_bp = hs->d_bp.used;
   }
   *out = hs;
   return PRB_OK;

@@ -51,6 +51,7 @@ struct prb_ctx {
   int64_t slow_hits = 0;       // extensions that went through the HBM-scratch fallback kernel
   int max_gap_caps = 128;      // largest diagonal capacity any gapped extension has needed
   bool keep_device_records = false; // final hit sets also keep their packed records in HBM (for prb_gather_hits)
+  size_t keep_hint_hits = 0, keep_hint_bp = 0; // bytes the last such hit set ended up with (KeepBuf::hint)
   prb::DevBuf d_expd, d_log, d_small, d_big;
   // Raccess workspaces
   prb::DevBuf ra_band, ra_vec, ra_codes, ra_desc, ra_acc, ra_cond;

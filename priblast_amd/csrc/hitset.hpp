@@ -40,23 +40,35 @@ struct PinnedBuf {
 };
 
 // Device buffer that grows and keeps what it holds (the packed records of the sub-batches of a
-// search, kept for the final hit gather).
+// search, kept for the final hit gather).  `hint` = what the last search of the context ended up with: the first
+// append allocates that much, so a steady stream of similar batches never grows.  A buffer that is outgrown is only
+// retired, not freed, until the hit set goes: hipFree waits for the whole device - for the accessibility kernels of
+// the next batch on the other stream as well (ten doublings per hit set cost 0.55 s per configs[2] step that way).
 struct KeepBuf {
   DevBuf b;
-  size_t used = 0;
+  size_t used = 0, hint = 0;
+  std::vector<DevBuf> retired;
   int append(const void *src_dev, size_t bytes, hipStream_t s) {
     if (used + bytes > b.cap) {
       DevBuf nb;
-      int rc = nb.ensure(std::max((used + bytes) * 2, (size_t)1 << 20));
+      int rc = nb.ensure(std::max({(used + bytes) * 2, hint + hint / 8, (size_t)1 << 20}));
       if (rc) return rc;
-      if (used) PRB_HIP(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
-      PRB_HIP(hipStreamSynchronize(s));
-      b.release();
+      if (used) {
+        PRB_HIP(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
+        PRB_HIP(hipStreamSynchronize(s));
+      }
+      if (b.p) retired.push_back(b);
       b = nb;
     }
     if (bytes) PRB_HIP(hipMemcpyAsync(static_cast<uint8_t *>(b.p) + used, src_dev, bytes, hipMemcpyDeviceToDevice, s));
     used += bytes;
     return PRB_OK;
+  }
+  void release() {
+    b.release();
+    for (DevBuf &r : retired) r.release();
+    retired.clear();
+    used = 0;
   }
 };
 
@@ -82,8 +94,8 @@ struct prb_hitset {
     if (ext_release) ext_release(ext_owner, ext_slot);
     if (d_hits.b.p || d_bp.b.p) {
       (void)hipSetDevice(device);
-      d_hits.b.release();
-      d_bp.b.release();
+      d_hits.release();
+      d_bp.release();
     }
   }
   int64_t counts[3] = {0, 0, 0};
