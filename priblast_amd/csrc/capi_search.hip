@@ -1415,7 +1415,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     // host copies of four per-hit arrays + the offsets, in one page-locked block that lives with the workspace (fresh
     // vectors of 3 MB each were an mmap, ~750 page faults and a munmap apiece, per sub-batch)
     const size_t NF = (size_t)nfin;
-    if ((rc = w.tb_pinned.ensure(NF * 4 * 3 + NF + 16 + (NF + 1) * 8))) return rc;
+    const size_t tb_bytes = NF * 4 * 3 + NF + 16 + (NF + 1) * 8;
+    if ((rc = w.tb_pinned.ensure(w.tb_pinned.cap >= tb_bytes ? tb_bytes : 2 * tb_bytes))) return rc;
     int64_t *off = static_cast<int64_t *>(w.tb_pinned.p);
     uint32_t *pre = reinterpret_cast<uint32_t *>(off + NF + 1); // index of each final hit's pre-gapped state in U
     int32_t *cnt = reinterpret_cast<int32_t *>(pre + NF);
@@ -1484,8 +1485,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     hs->drain->acquire(slot);
     const int64_t bp_base_pairs = hs->bp_ints_total / 2;
     const int64_t nbp_ints = opts.output_style == 0 ? nfin * 4 : total * 2;
-    if ((rc = w.packed.ensure((size_t)nfin * sizeof(prb_hit))) || (rc = w.pin_hits[slot].ensure((size_t)nfin * sizeof(prb_hit))) ||
-        (rc = w.pin_bp[slot].ensure((size_t)std::max<int64_t>(nbp_ints, 1) * 4)))
+    // (page-locking a fresh 50 MB block takes ~35 ms with the GPU idle: when a slot has to grow, to twice the need, so
+    // that the larger sub-batches to come still fit)
+    const size_t hit_bytes = (size_t)nfin * sizeof(prb_hit), bp_bytes = (size_t)std::max<int64_t>(nbp_ints, 1) * 4;
+    if ((rc = w.packed.ensure(hit_bytes)) || (rc = w.pin_hits[slot].ensure(w.pin_hits[slot].cap >= hit_bytes ? hit_bytes : 2 * hit_bytes)) ||
+        (rc = w.pin_bp[slot].ensure(w.pin_bp[slot].cap >= bp_bytes ? bp_bytes : 2 * bp_bytes)))
       return rc;
     const int32_t *bp_src;
     if (opts.output_style == 0) {
@@ -1648,6 +1652,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   hs->drain = &drain;
   const char *env = getenv("PRB_SEARCH_PAIRS");
   const double budget = env ? atof(env) : 4.0e8;
+  if (last_stage == 3) { // a stream of similar batches: the last hit set's size, with a twentieth to spare, up front
+    drain.hint_hits = ctx->host_hint_hits + ctx->host_hint_hits / 20;
+    drain.hint_bp = ctx->host_hint_bp + ctx->host_hint_bp / 20;
+  }
   int rc = drain.start();
   double wait_ms = 0;
   std::vector<int64_t> cbase, rbase, ebase;
@@ -1703,10 +1711,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     // the pinned candidates are reused by the next sub-batch: their upload must be over
     if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;
     q0 = q1;
-    if (q0 < nq) { // with a tenth to spare
+    if (q0 < nq) { // extrapolated from the queries done so far, with a tenth to spare (never below the hint from the last set)
       const double scale = 1.1 * (double)nq / (double)q0;
-      drain.hint_hits = (size_t)((double)hs->counts[2] * scale);
-      drain.hint_bp = (size_t)((double)hs->bp_ints_total * scale);
+      drain.hint_hits = std::max(drain.hint_hits.load(), (size_t)((double)hs->counts[2] * scale));
+      drain.hint_bp = std::max(drain.hint_bp.load(), (size_t)((double)hs->bp_ints_total * scale));
     }
   }
   producer.join();
@@ -1727,6 +1735,10 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   if (hs->on_device) {
     ctx->keep_hint_hits = hs->d_hits.used;
     ctx->keep_hint_bp = hs->d_bp.used;
+  }
+  if (last_stage == 3) {
+    ctx->host_hint_hits = hs->hits.size();
+    ctx->host_hint_bp = hs->bp.size();
   }
   *out = hs;
   return PRB_OK;

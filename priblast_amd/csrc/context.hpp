@@ -52,6 +52,7 @@ struct prb_ctx {
   int max_gap_caps = 128;      // largest diagonal capacity any gapped extension has needed
   bool keep_device_records = false; // final hit sets also keep their packed records in HBM (for prb_gather_hits)
   size_t keep_hint_hits = 0, keep_hint_bp = 0; // bytes the last such hit set ended up with (KeepBuf::hint)
+  size_t host_hint_hits = 0, host_hint_bp = 0; // hits / pair ints of the last final hit set (its vectors' first reserve)
   prb::DevBuf d_expd, d_log, d_small, d_big;
   // Raccess workspaces
   prb::DevBuf ra_band, ra_vec, ra_codes, ra_desc, ra_acc, ra_cond;
