@@ -58,7 +58,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)  # (buffers that grow with the largest sub-batch seen settle within two batches)
     ap.add_argument("--queries", type=int, default=int(os.environ.get("BENCH_QUERIES", 16)), help="queries per GPU per step")
     ap.add_argument("--db-seqs", type=int, default=int(os.environ.get("BENCH_DB_SEQS", 50000)))
     ap.add_argument("--length", type=int, default=int(os.environ.get("BENCH_LENGTH", 2000)))
