@@ -241,6 +241,8 @@ def main():
     # host threads for the per-query host work (suffix arrays, seed DFS, line formatting): share the box among the ranks
     # per pool of host threads (seed DFS, result lines: two are busy at a time), of this rank's share of the CPUs
     os.environ.setdefault("PRB_HOST_THREADS", str(max(2, min(32, host_cores() // (2 * max(world, 1))))))
+    if world > 1 and rank == 0:  # rank 0 alone writes the lines, for all ranks: half of the CPUs for that
+        os.environ.setdefault("PRB_FORMAT_THREADS", str(max(2, min(32, host_cores() // 2))))
     torch.cuda.set_device(local)
     multi = world > 1 or a.force_comm
     if world > 1:

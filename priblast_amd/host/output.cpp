@@ -14,6 +14,8 @@
 namespace prb {
 
 int format_threads() {
+  // (its own knob first: with one process per GPU only rank 0 writes lines - for all ranks - while every rank runs a seed DFS)
+  if (const char *e = std::getenv("PRB_FORMAT_THREADS")) return std::max(1, std::atoi(e));
   if (const char *e = std::getenv("PRB_HOST_THREADS")) return std::max(1, std::atoi(e));
   return default_host_threads();
 }

@@ -376,6 +376,14 @@ int ris_main(int argc, char **argv) {
     const int local = env_int("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", rank);
     const int dev = devices.empty() ? local : devices[(size_t)local % devices.size()];
     devices.assign(1, dev);
+    // The ranks of a node share its CPUs: every rank runs suffix arrays + a seed DFS, rank 0 alone writes the lines of all
+    // of them.  Unless the user says otherwise: half of the CPUs split over the ranks for the former, the other half for
+    // rank 0's formatting (WORLD_SIZE counts ranks on other nodes too - then this errs on the small side).
+    const int budget = prb_cpu_budget();
+    if (world > 1) {
+      setenv("PRB_HOST_THREADS", std::to_string(std::max(2, std::min(32, budget / (2 * world)))).c_str(), 0);
+      if (rank == 0) setenv("PRB_FORMAT_THREADS", std::to_string(std::max(2, std::min(32, budget / 2))).c_str(), 0);
+    }
   }
   if (devices.empty()) devices.push_back(0);
   std::vector<Worker> workers(devices.size());
