@@ -5,6 +5,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 
 #include <algorithm>
@@ -49,6 +50,43 @@ struct SearchWs {
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
       scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, laneScratch, pair0;
   std::vector<int64_t> pair0_host;
+  // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
+  // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
+  // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
+  // ~7 ms of bandwidth-bound work per configs[2] query beside the ~2 ms that the ~150 longest extensions of a query run
+  // alone (twice) and the final sort / filter / copies, instead of standing in line behind them.
+  struct FrontStage {
+    DevBuf cands, seed_qacc, pair0, keyA, keyB, valA, valB, sortTmp;
+    PinnedBuf pair0_pin;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool ahead = false;         // holds the first chunk of the sub-batch whose candidates are at `cd`, issued on `stream`
+    const CandDev *cd = nullptr;
+    int32_t nc = 0;
+    int64_t np = 0;
+    int init() {
+      if (stream) return PRB_OK;
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // (lo = the numerically largest = least urgent)
+      if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, lo) != hipSuccess ||
+          hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
+        set_error("hipStreamCreateWithPriority / hipEventCreate failed (seed front stage)");
+        return PRB_ERR_HIP;
+      }
+      return PRB_OK;
+    }
+    void release() {
+      if (stream) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamDestroy(stream);
+        (void)hipEventDestroy(done);
+        stream = nullptr;
+      }
+      for (DevBuf *b : {&cands, &seed_qacc, &pair0, &keyA, &keyB, &valA, &valB, &sortTmp}) b->release();
+      pair0_pin.release();
+      ahead = false;
+    }
+  } front;
   // results leave on a stream of their own: the next sub-batch does not queue behind 60 MB over PCIe
   hipStream_t copy_stream = nullptr;
   hipEvent_t packed_ready = nullptr, copy_done = nullptr;
@@ -63,12 +101,13 @@ struct SearchWs {
     }
     return PRB_OK;
   }
-  PinnedBuf pinned, cand_pinned, tb_pinned, pin_hits[2], pin_bp[2];
+  PinnedBuf pinned, cand_pinned[2], tb_pinned, pin_hits[2], pin_bp[2];
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
                       &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &laneScratch, &pair0})
       b->release();
+    front.release();
     if (copy_stream) {
       (void)hipStreamSynchronize(copy_stream);
       (void)hipStreamDestroy(copy_stream);
@@ -77,7 +116,8 @@ struct SearchWs {
       copy_stream = nullptr;
     }
     pinned.release();
-    cand_pinned.release();
+    cand_pinned[0].release();
+    cand_pinned[1].release();
     tb_pinned.release();
     for (int i = 0; i < 2; i++) {
       pin_hits[i].release();
@@ -951,10 +991,89 @@ static int download_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, 
   return PRB_OK;
 }
 
+// Candidates [c0, c1) of a sub-batch = its next chunk: as many as fit the pair budget (and the one-pass form's record)
+static int32_t chunk_end(const CandDev *cd, int32_t ncand, int32_t c0, double chunk_pairs, double *pairs_out) {
+  int32_t c1 = c0;
+  double acc = 0;
+  while (c1 < ncand) {
+    const double pairs = (double)(cd[c1].ep_q - cd[c1].sp_q + 1) * (double)(cd[c1].ep_db - cd[c1].sp_db + 1);
+    if (c1 > c0 && (acc + pairs > chunk_pairs || c1 - c0 >= kMaxFusedCands)) break;
+    acc += pairs;
+    c1++;
+  }
+  *pairs_out = acc;
+  return c1;
+}
+struct SeedKnobs {
+  double chunk_pairs;
+  int row_shift;
+  bool fused;
+};
+static SeedKnobs seed_knobs() {
+  const char *cenv = getenv("PRB_SEARCH_CHUNK_PAIRS");
+  const char *benv = getenv("PRB_SEARCH_PAIRS");
+  const char *rsenv = getenv("PRB_SEED_ROW_SHIFT");
+  const char *fenv = getenv("PRB_SEED_FUSED"); // 0: seeds written as a list, extended and thinned in separate passes
+  return SeedKnobs{cenv ? atof(cenv) : (benv ? atof(benv) : 4.0e8), rsenv ? std::min(atoi(rsenv), 30) : 7, !(fenv && atoi(fenv) == 0)};
+}
+
+// The front of the one-pass seed path (SearchWs::FrontStage) for the chunk whose candidates - row0 / qoff relative to
+// the chunk - are the nc entries at cd (page-locked): everything is issued on `s`.  *np_out = its pairs, or -1 when a
+// candidate has more query entries than a pair's value has bits for (nothing is issued then: the list form takes it).
+static int issue_front(SearchWs &w, const prb_qbatch *qb, const PageDev &pd, int delta, int row_shift, const CandDev *cd, int32_t nc,
+                       int64_t cents, hipStream_t s, int64_t *np_out) {
+  SearchWs::FrontStage &F = w.front;
+  int rc;
+  *np_out = -1;
+  if ((rc = F.pair0_pin.ensure(((size_t)nc + 1) * 8))) return rc;
+  int64_t *pair0 = static_cast<int64_t *>(F.pair0_pin.p);
+  int64_t np = 0;
+  for (int32_t c = 0; c < nc; c++) {
+    const int64_t qw = cd[c].ep_q - cd[c].sp_q + 1;
+    if (qw > kMaxFusedEntries) return PRB_OK;
+    pair0[c] = np;
+    np += qw * (int64_t)(cd[c].ep_db - cd[c].sp_db + 1);
+  }
+  pair0[nc] = np;
+  const size_t NP = (size_t)np;
+  const int qmin = cd[0].query;
+  const int dbits = bits_for(std::max<int64_t>(1, ((int64_t)pd.nchars - 1) >> row_shift));
+  const int kbits = dbits + bits_for(std::max<int64_t>(1, (int64_t)cd[nc - 1].query - qmin));
+  const bool wide = kbits > 32;
+  if ((rc = F.cands.ensure((size_t)nc * sizeof(CandDev))) || (rc = F.seed_qacc.ensure((size_t)std::max<int64_t>(cents, 1) * 8)) ||
+      (rc = F.pair0.ensure(((size_t)nc + 1) * 8)) || (rc = F.keyA.ensure(NP * (wide ? 8 : 4))) || (rc = F.keyB.ensure(NP * (wide ? 8 : 4))) ||
+      (rc = F.valA.ensure(NP * 8)) || (rc = F.valB.ensure(NP * 8)))
+    return rc;
+  PRB_HIP(hipMemcpyAsync(F.cands.p, cd, (size_t)nc * sizeof(CandDev), hipMemcpyHostToDevice, s));
+  PRB_HIP(hipMemcpyAsync(F.pair0.p, pair0, ((size_t)nc + 1) * 8, hipMemcpyHostToDevice, s));
+  PRB_HIP(launch_seed_qacc(F.cands.as<CandDev>(), nc, cents, qb->view, delta, F.seed_qacc.as<double>(), s));
+  PRB_HIP(launch_pair_keys(F.cands.as<CandDev>(), F.pair0.as<int64_t>(), nc, np, pd, qmin, row_shift, dbits, wide, F.keyA.p,
+                           F.valA.as<uint64_t>(), s));
+  size_t tmp = 0;
+  if (wide) {
+    PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, F.keyA.as<uint64_t>(), F.keyB.as<uint64_t>(), F.valA.as<uint64_t>(),
+                                      F.valB.as<uint64_t>(), NP, 0, (unsigned)kbits, s));
+    if ((rc = F.sortTmp.ensure(tmp))) return rc;
+    PRB_HIP(rocprim::radix_sort_pairs(F.sortTmp.p, tmp, F.keyA.as<uint64_t>(), F.keyB.as<uint64_t>(), F.valA.as<uint64_t>(),
+                                      F.valB.as<uint64_t>(), NP, 0, (unsigned)kbits, s));
+  } else {
+    PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, F.keyA.as<uint32_t>(), F.keyB.as<uint32_t>(), F.valA.as<uint64_t>(),
+                                      F.valB.as<uint64_t>(), NP, 0, (unsigned)kbits, s));
+    if ((rc = F.sortTmp.ensure(tmp))) return rc;
+    PRB_HIP(rocprim::radix_sort_pairs(F.sortTmp.p, tmp, F.keyA.as<uint32_t>(), F.keyB.as<uint32_t>(), F.valA.as<uint64_t>(),
+                                      F.valB.as<uint64_t>(), NP, 0, (unsigned)kbits, s));
+  }
+  *np_out = np;
+  return PRB_OK;
+}
+
 // One sub-batch of queries through the GPU stages.  cd (pinned host memory) = its seed candidates in
-// query order, row0 filled in; nrows = their database SA entries in total.
+// query order, row0 filled in; nrows = their database SA entries in total.  `front_free` (may be empty) is called
+// at most once, behind the LDS tiers of the gapped cascade (the front stage's buffers are long free by then): the
+// caller's chance to issue the front of the NEXT sub-batch ahead (issue_front on SearchWs::front.stream, SearchWs::front.ahead set).
 static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, const prb_ris_opts &opts, int last_stage,
-                        const CandDev *cd, int64_t ncand64, int64_t nrows, int64_t nqent, prb_hitset *hs) {
+                        const CandDev *cd, int64_t ncand64, int64_t nrows, int64_t nqent, prb_hitset *hs,
+                        const std::function<void()> &front_free) {
   SearchWs &w = ws_of(ctx);
   const SearchConst &sc = static_cast<SearchConstMem *>(ctx->search_const)->view;
   const DbPage &pg = db->pages[page];
@@ -982,25 +1101,17 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // entry) pairs each; the survivors of all chunks, in candidate order, are what the sort and the redundancy filter
   // then see.  So the seed pools are bounded by the pair budget whatever a single query brings - a 100 kb query
   // against a 100 M character page has 1e10 seeds - while the filter still runs over whole queries.
-  const char *cenv = getenv("PRB_SEARCH_CHUNK_PAIRS");
-  const char *benv = getenv("PRB_SEARCH_PAIRS");
-  const double chunk_pairs = cenv ? atof(cenv) : (benv ? atof(benv) : 4.0e8);
-  // rows in (query, database position >> row_shift) order, see k_row_key; PRB_SEED_ROW_SHIFT = -1 keeps suffix-array order
-  const char *rsenv = getenv("PRB_SEED_ROW_SHIFT");
-  const int row_shift = rsenv ? std::min(atoi(rsenv), 30) : 7;
-  const char *fenv = getenv("PRB_SEED_FUSED"); // 0: seeds written as a list, extended and thinned in separate passes
-  const bool fused = !(fenv && atoi(fenv) == 0);
+  // rows / pairs in (query, database position >> row_shift) order, see k_row_key; PRB_SEED_ROW_SHIFT = -1 keeps suffix-array order
+  const SeedKnobs knobs = seed_knobs();
+  const double chunk_pairs = knobs.chunk_pairs;
+  const int row_shift = knobs.row_shift;
+  const bool fused = knobs.fused;
+  if ((rc = w.front.init())) return rc;
   CandDev *cdm = const_cast<CandDev *>(cd); // (the caller's staging buffer: each candidate is rebased once, for its chunk)
   int64_t m1 = 0;
   for (int32_t c0 = 0; c0 < ncand;) {
-    int32_t c1 = c0;
     double acc = 0;
-    while (c1 < ncand) {
-      const double pairs = (double)(cd[c1].ep_q - cd[c1].sp_q + 1) * (double)(cd[c1].ep_db - cd[c1].sp_db + 1);
-      if (c1 > c0 && (acc + pairs > chunk_pairs || c1 - c0 >= kMaxFusedCands)) break;
-      acc += pairs;
-      c1++;
-    }
+    const int32_t c1 = chunk_end(cd, ncand, c0, chunk_pairs, &acc);
     const int32_t nc = c1 - c0;
     const int64_t row_base = cd[c0].row0, ent_base = cd[c0].qoff;
     const int64_t crows = (c1 < ncand ? cd[c1].row0 : nrows) - row_base, cents = (c1 < ncand ? cd[c1].qoff : nqent) - ent_base;
@@ -1008,55 +1119,23 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       cdm[c].row0 -= row_base;
       cdm[c].qoff -= ent_base;
     }
-    if ((rc = w.cands.ensure((size_t)nc * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(crows + 1) * 4)) ||
-        (rc = w.row_off.ensure((size_t)(crows + 1) * 8)) || (rc = w.row_cand.ensure((size_t)(crows + 1) * 4)) ||
-        (rc = w.seed_qacc.ensure((size_t)std::max<int64_t>(cents, 1) * 8)))
-      return rc;
-    PRB_HIP(hipMemcpyAsync(w.cands.p, cd + c0, (size_t)nc * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = ctx->time_begin())) return rc;
-    // one extra zero entry so that the exclusive scan over crows+1 values also yields the total
-    PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + crows, 0, 4, ctx->stream));
-    PRB_HIP(launch_seed_qacc(w.cands.as<CandDev>(), nc, cents, qb->view, delta, w.seed_qacc.as<double>(), ctx->stream));
     // ---- seeds -> hits under the -f threshold in one pass over the sorted pairs (search_kernels.hip) ----
-    bool fuse = fused && last_stage != 1 && row_shift >= 0 && acc < 4.0e9;
-    if (fuse) {
-      w.pair0_host.resize((size_t)nc + 1);
-      int64_t np = 0;
-      for (int32_t c = 0; c < nc && fuse; c++) {
-        const int64_t qw = cd[c0 + c].ep_q - cd[c0 + c].sp_q + 1;
-        if (qw > kMaxFusedEntries) fuse = false;
-        w.pair0_host[(size_t)c] = np;
-        np += qw * (int64_t)(cd[c0 + c].ep_db - cd[c0 + c].sp_db + 1);
-      }
-      w.pair0_host[(size_t)nc] = np;
-    }
-    if (fuse) {
-      const int64_t np = w.pair0_host[(size_t)nc];
-      const size_t NP = (size_t)np;
-      const int qmin = cd[c0].query;
-      const int dbits = bits_for(std::max<int64_t>(1, ((int64_t)pd.nchars - 1) >> row_shift));
-      const int kbits = dbits + bits_for(std::max<int64_t>(1, (int64_t)cd[c1 - 1].query - qmin));
-      const bool wide = kbits > 32;
-      if ((rc = w.pair0.ensure(((size_t)nc + 1) * 8)) || (rc = w.kP.ensure(NP * 8)) || (rc = w.kTmp2.ensure(NP * 8)) ||
-          (rc = w.kE.ensure(NP * 8)) || (rc = w.kTmp.ensure(NP * 8)) || (rc = w.count.ensure(16)))
-        return rc;
-      PRB_HIP(hipMemcpyAsync(w.pair0.p, w.pair0_host.data(), ((size_t)nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-      PRB_HIP(launch_pair_keys(w.cands.as<CandDev>(), w.pair0.as<int64_t>(), nc, np, pd, qmin, row_shift, dbits, wide, w.kP.p,
-                               w.kE.as<uint64_t>(), ctx->stream));
-      size_t tmp = 0;
-      if (wide) {
-        PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.kE.as<uint64_t>(),
-                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
-        if ((rc = w.sortTmp.ensure(tmp))) return rc;
-        PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint64_t>(), w.kTmp2.as<uint64_t>(), w.kE.as<uint64_t>(),
-                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
+    int64_t np = -1;
+    if (fused && last_stage != 1 && row_shift >= 0 && acc < 4.0e9) {
+      if ((rc = ctx->time_begin())) return rc;
+      SearchWs::FrontStage &F = w.front;
+      if (c0 == 0 && F.ahead && F.cd == cd && F.nc == nc) { // issued while the last sub-batch was extended: wait for it
+        np = F.np;
+        PRB_HIP(hipStreamWaitEvent(ctx->stream, F.done, 0));
       } else {
-        PRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w.kP.as<uint32_t>(), w.kTmp2.as<uint32_t>(), w.kE.as<uint64_t>(),
-                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
-        if ((rc = w.sortTmp.ensure(tmp))) return rc;
-        PRB_HIP(rocprim::radix_sort_pairs(w.sortTmp.p, tmp, w.kP.as<uint32_t>(), w.kTmp2.as<uint32_t>(), w.kE.as<uint64_t>(),
-                                          w.kTmp.as<uint64_t>(), NP, 0, (unsigned)kbits, ctx->stream));
+        if (F.ahead) PRB_HIP(hipStreamSynchronize(F.stream)); // (not what was expected: its buffers are taken over)
+        if ((rc = issue_front(w, qb, pd, delta, row_shift, cd + c0, nc, cents, ctx->stream, &np))) return rc;
       }
+      F.ahead = false;
+    }
+    if (np >= 0) {
+      SearchWs::FrontStage &F = w.front;
+      if ((rc = w.count.ensure(16))) return rc;
       if ((rc = ctx->time_end("seed", 2))) return rc;
       if ((rc = ctx->time_begin())) return rc;
       const int64_t nsl = fused_slices(np);
@@ -1065,7 +1144,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         return rc;
       PRB_HIP(hipMemsetAsync(w.count.p, 0, 16, ctx->stream));
       PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + nsl, 0, 4, ctx->stream));
-      PRB_HIP(launch_seed_extend(w.cands.as<CandDev>(), w.kTmp.as<uint64_t>(), np, qb->view, pd, sc, eo, w.seed_qacc.as<double>(),
+      PRB_HIP(launch_seed_extend(F.cands.as<CandDev>(), F.valB.as<uint64_t>(), np, qb->view, pd, sc, eo, F.seed_qacc.as<double>(),
                                  opts.interaction_threshold, max_qlen, w.hitsA.p, w.row_count.as<int32_t>(), w.count.as<uint64_t>(),
                                  ctx->stream));
       {
@@ -1097,6 +1176,16 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       }
       continue;
     }
+    // ---- the list form: seeds counted, written, extended and thinned in passes of their own ----
+    if ((rc = w.cands.ensure((size_t)nc * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(crows + 1) * 4)) ||
+        (rc = w.row_off.ensure((size_t)(crows + 1) * 8)) || (rc = w.row_cand.ensure((size_t)(crows + 1) * 4)) ||
+        (rc = w.seed_qacc.ensure((size_t)std::max<int64_t>(cents, 1) * 8)))
+      return rc;
+    PRB_HIP(hipMemcpyAsync(w.cands.p, cd + c0, (size_t)nc * sizeof(CandDev), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx->time_begin())) return rc;
+    // one extra zero entry so that the exclusive scan over crows+1 values also yields the total
+    PRB_HIP(hipMemsetAsync(w.row_count.as<int32_t>() + crows, 0, 4, ctx->stream));
+    PRB_HIP(launch_seed_qacc(w.cands.as<CandDev>(), nc, cents, qb->view, delta, w.seed_qacc.as<double>(), ctx->stream));
     // the rows in the order of (query, database position) - not for the seed-stage output, which keeps the reference's
     // emission order (candidate, database SA entry, query SA entry) - see k_row_key
     const uint32_t *row_perm = nullptr;
@@ -1329,6 +1418,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 4 * 3, ctx->stream));
   }
   static const char *const kTierTimer[5] = {"gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow"};
+  bool front_called = false;
   {
     const uint32_t *cur = nullptr; // all of U
     int64_t m = nung;
@@ -1353,6 +1443,10 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     }
     for (size_t c = 0; c < cascade.size() && m > 0; c++) {
       const int tier = cascade[c];
+      if (tier == kWaveTier && front_free && !front_called) { // (see below: the longest extensions run nearly alone)
+        front_free();
+        front_called = true;
+      }
       if ((rc = ctx->time_begin())) return rc;
       if (tier == kWaveTier) {
         hs->slow_hits += m;
@@ -1375,6 +1469,15 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     }
   }
 
+  // The front of the NEXT sub-batch's seed path (bandwidth-bound, ~7 ms per configs[2] query) goes out here at the latest:
+  // beside what is left of this sub-batch - the ~150 longest extensions on a wavefront each (2 ms, and 2 ms again for
+  // their base pairs), the final sort and filter of a few hundred thousand hits, the copies to the host - the GPU is
+  // nearly idle.  (Issued right behind k_seed_extend, even on a stream of the lowest priority, it cost the gapped
+  // tiers 290 ms per step: its workgroups take LDS and wave slots that tier 0 fills completely.)
+  if (front_free && !front_called) {
+    front_free();
+    front_called = true;
+  }
   // ---- final sort + filter (hits above the -g threshold dropped first) ----
   int64_t m2 = 0;
   if ((rc = ctx->time_begin())) return rc;
@@ -1659,50 +1762,113 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
   int rc = drain.start();
   double wait_ms = 0;
   std::vector<int64_t> cbase, rbase, ebase;
-  for (int32_t q0 = 0; q0 < nq && rc == PRB_OK;) {
-    const auto tw0 = std::chrono::steady_clock::now();
-    int32_t q1 = q0;
-    double acc = 0;
-    for (;;) { // queries [q0, q1) of this sub-batch: as many as fit the pair budget
-      if (q1 >= nq) break;
-      wait_for(q1);
-      if (q1 > q0 && acc + qpairs[q1] > budget) break;
-      acc += qpairs[q1];
-      q1++;
-    }
-    wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
-    // the sub-batch's candidates, converted straight into pinned memory (queries in parallel)
-    const int32_t nb = q1 - q0;
+  // the candidates of queries [a, b) converted straight into page-locked memory (queries in parallel), rows and query
+  // entries numbered from 0
+  struct SubBatch {
+    int32_t q0 = 0, q1 = 0;
+    CandDev *cd = nullptr;
+    int64_t ncand = 0, nrows = 0, nqent = 0;
+  };
+  auto convert = [&](int32_t a, int32_t b, PinnedBuf &pin, SubBatch &out) -> int {
+    const int32_t nb = b - a;
     cbase.assign((size_t)nb + 1, 0);
     rbase.assign((size_t)nb + 1, 0);
     ebase.assign((size_t)nb + 1, 0);
     for (int32_t k = 0; k < nb; k++) {
-      cbase[k + 1] = cbase[k] + (int64_t)per_q[q0 + k].size();
-      rbase[k + 1] = rbase[k] + qrows[q0 + k];
-      ebase[k + 1] = ebase[k] + qents[q0 + k];
+      cbase[k + 1] = cbase[k] + (int64_t)per_q[a + k].size();
+      rbase[k + 1] = rbase[k] + qrows[a + k];
+      ebase[k + 1] = ebase[k] + qents[a + k];
     }
-    const int64_t ncand = cbase[nb], nrows = rbase[nb], nqent = ebase[nb];
-    if ((rc = wsp.cand_pinned.ensure((size_t)std::max<int64_t>(ncand, 1) * sizeof(CandDev)))) break;
-    CandDev *cd = static_cast<CandDev *>(wsp.cand_pinned.p);
-    {
-      HostTimer ht(ctx, "host_cands");
+    out.q0 = a;
+    out.q1 = b;
+    out.ncand = cbase[nb];
+    out.nrows = rbase[nb];
+    out.nqent = ebase[nb];
+    if (int r = pin.ensure((size_t)std::max<int64_t>(out.ncand, 1) * sizeof(CandDev))) return r;
+    CandDev *cd = static_cast<CandDev *>(pin.p);
+    out.cd = cd;
+    HostTimer ht(ctx, "host_cands");
 #pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(8, host_threads(nb)))
-      for (int32_t k = 0; k < nb; k++) {
-        std::vector<SeedCandidate> &v = per_q[q0 + k];
-        CandDev *out = cd + cbase[k];
-        int64_t row = rbase[k], ent = ebase[k];
-        for (size_t i = 0; i < v.size(); i++) {
-          const SeedCandidate &c = v[i];
-          out[i] = CandDev{c.sp_q, c.ep_q, c.sp_db, c.ep_db, c.length, c.query, c.score, row, ent};
-          row += (int64_t)c.ep_db - c.sp_db + 1;
-          ent += (int64_t)c.ep_q - c.sp_q + 1;
-        }
-        std::vector<SeedCandidate>().swap(v);
+    for (int32_t k = 0; k < nb; k++) {
+      std::vector<SeedCandidate> &v = per_q[a + k];
+      CandDev *o = cd + cbase[k];
+      int64_t row = rbase[k], ent = ebase[k];
+      for (size_t i = 0; i < v.size(); i++) {
+        const SeedCandidate &c = v[i];
+        o[i] = CandDev{c.sp_q, c.ep_q, c.sp_db, c.ep_db, c.length, c.query, c.score, row, ent};
+        row += (int64_t)c.ep_db - c.sp_db + 1;
+        ent += (int64_t)c.ep_q - c.sp_q + 1;
       }
+      std::vector<SeedCandidate>().swap(v);
     }
+    return PRB_OK;
+  };
+  const SeedKnobs knobs = seed_knobs();
+  const PageDev &pdv = db->mem[(size_t)db->slot_of_page[(size_t)page]].view;
+  const bool front_ahead = !getenv("PRB_NO_FRONT_AHEAD");
+  SubBatch next; // the sub-batch behind the current one, when it has been prepared ahead (next.q1 > next.q0)
+  int parity = 0;
+  for (int32_t q0 = 0; q0 < nq && rc == PRB_OK;) {
+    SubBatch cur;
+    if (next.q1 > next.q0 && next.q0 == q0) {
+      cur = next;
+    } else {
+      const auto tw0 = std::chrono::steady_clock::now();
+      int32_t q1 = q0;
+      double acc = 0;
+      for (;;) { // queries [q0, q1) of this sub-batch: as many as fit the pair budget
+        if (q1 >= nq) break;
+        wait_for(q1);
+        if (q1 > q0 && acc + qpairs[q1] > budget) break;
+        acc += qpairs[q1];
+        q1++;
+      }
+      wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+      if ((rc = convert(q0, q1, wsp.cand_pinned[parity], cur))) break;
+    }
+    next = SubBatch{};
+    const int32_t q1 = cur.q1;
+    const CandDev *cd = cur.cd;
+    const int64_t ncand = cur.ncand, nrows = cur.nrows, nqent = cur.nqent;
+    // While this sub-batch is sorted, filtered and extended: the candidates of the next one into the other page-locked
+    // buffer and the front of its seed path onto the low-priority stream - if its queries' DFS is done (no waiting here).
+    std::function<void()> front_free = [&]() {
+      if (!front_ahead || q1 >= nq || last_stage == 1 || !knobs.fused || knobs.row_shift < 0) return;
+      int32_t q2 = q1;
+      double acc = 0;
+      for (;;) {
+        if (q2 >= nq) break;
+        if (!plan.done[q2].load(std::memory_order_acquire)) return; // (the main loop will wait for it, and take it from there)
+        if (q2 > q1 && acc + qpairs[q2] > budget) break;
+        acc += qpairs[q2];
+        q2++;
+      }
+      SubBatch nb;
+      if (convert(q1, q2, wsp.cand_pinned[parity ^ 1], nb) != PRB_OK) return; // (candidates are converted once: `next` must be set)
+      next = nb;
+      if (nb.ncand == 0 || nb.ncand > INT32_MAX) return;
+      double pairs = 0;
+      const int32_t c1 = chunk_end(nb.cd, (int32_t)nb.ncand, 0, knobs.chunk_pairs, &pairs);
+      if (pairs >= 4.0e9) return;
+      const int64_t cents = (c1 < nb.ncand ? nb.cd[c1].qoff : nb.nqent) - nb.cd[0].qoff;
+      SearchWs::FrontStage &F = wsp.front;
+      int64_t np = -1;
+      if (issue_front(wsp, qb, pdv, db->hdr.min_accessible_length, knobs.row_shift, nb.cd, c1, cents, F.stream, &np) != PRB_OK || np < 0) {
+        (void)hipStreamSynchronize(F.stream); // (whatever part of it was issued is not used)
+        return;
+      }
+      if (hipEventRecord(F.done, F.stream) != hipSuccess) {
+        (void)hipStreamSynchronize(F.stream);
+        return;
+      }
+      F.ahead = true;
+      F.cd = nb.cd;
+      F.nc = c1;
+      F.np = np;
+    };
     {
       HostTimer ht(ctx, "host_search_range");
-      rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, nqent, hs);
+      rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, nqent, hs, front_free);
       if (rc == PRB_ERR_NOMEM) // (the seed pools are bounded by the chunk budget; what grows with a query is the list behind -f)
         set_error(std::string(prb_last_error()) + " - the hits of queries " + std::to_string(q0) + ".." + std::to_string(q1 - 1) +
                   " that pass -f against this page, with the gapped extension's state, do not fit the device: build the database in "
@@ -1711,11 +1877,16 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     // the pinned candidates are reused by the next sub-batch: their upload must be over
     if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;
     q0 = q1;
+    parity ^= 1;
     if (q0 < nq) { // extrapolated from the queries done so far, with a tenth to spare (never below the hint from the last set)
       const double scale = 1.1 * (double)nq / (double)q0;
       drain.hint_hits = std::max(drain.hint_hits.load(), (size_t)((double)hs->counts[2] * scale));
       drain.hint_bp = std::max(drain.hint_bp.load(), (size_t)((double)hs->bp_ints_total * scale));
     }
+  }
+  if (wsp.front.stream && wsp.front.ahead) { // (an error on the way: nothing of a front issued ahead stays in flight)
+    (void)hipStreamSynchronize(wsp.front.stream);
+    wsp.front.ahead = false;
   }
   producer.join();
   {

@@ -108,6 +108,7 @@ SEED_PATHS = {
     "sa_order": {"PRB_SEED_ROW_SHIFT": "-1"},     # rows in suffix-array order (the reference's emission order)
     "fused_exact": {"PRB_SEED_ROW_SHIFT": "0"},
     "fused_coarse": {"PRB_SEED_ROW_SHIFT": "14"},
+    "fused_in_line": {"PRB_NO_FRONT_AHEAD": "1"},  # pair keys + sort of a sub-batch not issued ahead, beside the one before it
 }
 
 
@@ -122,7 +123,7 @@ def test_candidate_chunks_and_seed_paths_are_transparent(ctx, golden_dir, monkey
     db = capi.Db(ctx, os.path.join(golden_dir, "mixdb"))
     qb = capi.QBatch(ctx, seqs, db.repeat_flag)
     qb.accessibility(db.W, db.delta)
-    knobs = ("PRB_SEARCH_CHUNK_PAIRS", "PRB_SEED_FUSED", "PRB_SEED_ROW_SHIFT")
+    knobs = ("PRB_SEARCH_CHUNK_PAIRS", "PRB_SEED_FUSED", "PRB_SEED_ROW_SHIFT", "PRB_NO_FRONT_AHEAD")
 
     def run(stage, env):
         for k in knobs:
