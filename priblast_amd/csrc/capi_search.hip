@@ -790,6 +790,7 @@ namespace prb {
 // Field bounds of the hits of one sub-batch, for the one-key sort
 struct SortBounds {
   int32_t qmin = 0, qspan = 1, max_qlen = 0, max_dblen = 0, nchars = 0;
+  int32_t eq_len_max = 0; // > 0: every hit of the list has q_len = db_len <= this (the one-pass seed path reports it)
 };
 static int bits_for(int64_t max_value) {
   int b = 1;
@@ -805,11 +806,12 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitRec *recs, HitSoA out, 
     // one stable radix sort over a packed key + a pass over the runs of identical coordinates
     PackedKeyInfo f;
     f.qmin = sb.qmin;
-    f.lmax = std::max(sb.max_qlen, sb.max_dblen);
+    f.one_len = sb.eq_len_max > 0;
+    f.lmax = f.one_len ? sb.eq_len_max : std::max(sb.max_qlen, sb.max_dblen);
     f.bl = bits_for(f.lmax);
     f.bq = bits_for(sb.max_qlen);
     f.bd = bits_for(sb.nchars);
-    const int total = 2 * f.bl + f.bq + f.bd + bits_for(sb.qspan - 1);
+    const int total = (f.one_len ? 1 : 2) * f.bl + f.bq + f.bd + bits_for(sb.qspan - 1);
     if (total <= 64 && f.lmax <= 65535 && !getenv("PRB_SORT_FOUR_KEYS")) {
       if ((rc = w.kP.ensure(N * 8)) || (rc = w.kTmp2.ensure(N * 8)) || (rc = w.kE.ensure(N * 8)) || (rc = w.kTmp.ensure(N * 8)) ||
           (rc = w.idxA.ensure(N * 4)) || (rc = w.idxB.ensure(N * 4)) || (rc = w.pending.ensure(16)))
@@ -1108,7 +1110,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   const bool fused = knobs.fused;
   if ((rc = w.front.init())) return rc;
   CandDev *cdm = const_cast<CandDev *>(cd); // (the caller's staging buffer: each candidate is rebased once, for its chunk)
-  int64_t m1 = 0;
+  int64_t m1 = 0, one_pass_maxlen = 0;
+  bool all_one_pass = true; // every chunk through k_seed_extend: lengths known, q_len = db_len
   for (int32_t c0 = 0; c0 < ncand;) {
     double acc = 0;
     const int32_t c1 = chunk_end(cd, ncand, c0, chunk_pairs, &acc);
@@ -1156,10 +1159,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         PRB_HIP(rocprim::exclusive_scan(w.scanTmp.p, tmp2, in, w.row_off.as<int64_t>(), (int64_t)0, (size_t)nsl + 1,
                                         rocprim::plus<int64_t>(), ctx->stream));
       }
-      uint64_t cnt[2] = {0, 0};
-      PRB_HIP(hipMemcpyAsync(&cnt[0], w.count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      uint64_t cnt[2] = {0, 0}, seeds_maxlen[2] = {0, 0};
+      PRB_HIP(hipMemcpyAsync(seeds_maxlen, w.count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
       PRB_HIP(hipMemcpyAsync(&cnt[1], w.row_off.as<int64_t>() + nsl, 8, hipMemcpyDeviceToHost, ctx->stream));
       PRB_HIP(hipStreamSynchronize(ctx->stream));
+      cnt[0] = seeds_maxlen[0];
+      one_pass_maxlen = std::max<int64_t>(one_pass_maxlen, (int64_t)seeds_maxlen[1]);
       if (cnt[1] > 0) {
         if ((rc = reserve_recs(ctx, w.hitsB, m1, (int64_t)cnt[1]))) return rc;
         PRB_HIP(launch_collect_slices(w.hitsA.p, w.row_count.as<int32_t>(), w.row_off.as<int64_t>(), nsl, w.hitsB.as<HitRec>() + m1,
@@ -1177,6 +1182,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       continue;
     }
     // ---- the list form: seeds counted, written, extended and thinned in passes of their own ----
+    all_one_pass = false;
     if ((rc = w.cands.ensure((size_t)nc * sizeof(CandDev))) || (rc = w.row_count.ensure((size_t)(crows + 1) * 4)) ||
         (rc = w.row_off.ensure((size_t)(crows + 1) * 8)) || (rc = w.row_cand.ensure((size_t)(crows + 1) * 4)) ||
         (rc = w.seed_qacc.ensure((size_t)std::max<int64_t>(cents, 1) * 8)))
@@ -1271,7 +1277,9 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   HitSoA B = carve_hits(w.hitsC, m1);
   uint32_t *perm = nullptr;
   if ((rc = ctx->time_begin())) return rc;
-  if ((rc = sort_hits(ctx, w, w.hitsB.as<HitRec>(), B, m1, qb->nq, sb, &perm))) return rc;
+  SortBounds sb1 = sb; // hits extended without gaps have one length: the key is 11 + (11 - bits of the longest) bits shorter
+  if (all_one_pass && one_pass_maxlen > 0 && !getenv("PRB_SORT_TWO_LENGTHS")) sb1.eq_len_max = (int32_t)one_pass_maxlen;
+  if ((rc = sort_hits(ctx, w, w.hitsB.as<HitRec>(), B, m1, qb->nq, sb1, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
   int64_t nung = 0;
   if ((rc = ctx->time_begin())) return rc;

@@ -544,7 +544,7 @@ struct FuseArgs {
   double thr;
   SliceRec *slices;        // kFusePairs per workgroup
   int32_t *slice_count;    // records in each slice
-  unsigned long long *nseed; // += seeds
+  unsigned long long *nseed; // [0] += seeds, [1] = max(., length of the longest hit kept)
   int qcap;
 };
 
@@ -556,13 +556,14 @@ template <int kAhead>
 __global__ __launch_bounds__(kBlock) void k_seed_extend(FuseArgs f, QBatchDev qb, PageDev pg, SearchConst sc, ExtOpts o) {
   extern __shared__ __align__(16) uint8_t ungapped_smem[];
   __shared__ int32_t s_tab[kUtTotal];
-  __shared__ unsigned s_kept, s_seeds;
+  __shared__ unsigned s_kept, s_seeds, s_maxlen;
   const int64_t b0 = (int64_t)blockIdx.x * kFusePairs;
   if (b0 >= f.npairs) return;
   const int64_t b1 = (b0 + kFusePairs < f.npairs ? b0 + kFusePairs : f.npairs) - 1;
   if (threadIdx.x == 0) {
     s_kept = 0;
     s_seeds = 0;
+    s_maxlen = 0;
   }
   for (int t = threadIdx.x; t < kUtTotal; t += kBlock)
     s_tab[t] = t < kUtInternal   ? sc.stack37[t]
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void k_seed_extend(FuseArgs f, QBatchDev qb
   __syncthreads();
   const int lane = threadIdx.x & 63;
   SliceRec *slice = f.slices + b0;
-  unsigned nseed = 0;
+  unsigned nseed = 0, maxlen = 0; // (the longest hit kept: the sort behind this packs the lengths into as many bits)
   for (int it = 0; it < kFusePer; it++) {
     const int64_t x = b0 + (int64_t)it * kBlock + threadIdx.x;
     bool keep = false;
@@ -639,15 +640,22 @@ __global__ __launch_bounds__(kBlock) void k_seed_extend(FuseArgs f, QBatchDev qb
         r.e_hyb = w.e_hyb;
         r.e_tot = w.e_tot;
         slice[basepos + (unsigned)__popcll(mask & ((1ull << lane) - 1))] = r;
+        maxlen = (unsigned)w.len > maxlen ? (unsigned)w.len : maxlen;
       }
     }
   }
-  for (int d = 32; d > 0; d >>= 1) nseed += (unsigned)__shfl_down((int)nseed, d);
+  for (int d = 32; d > 0; d >>= 1) {
+    nseed += (unsigned)__shfl_down((int)nseed, d);
+    const unsigned o = (unsigned)__shfl_down((int)maxlen, d);
+    maxlen = o > maxlen ? o : maxlen;
+  }
   if (lane == 0 && nseed) atomicAdd(&s_seeds, nseed);
+  if (lane == 0 && maxlen) atomicMax(&s_maxlen, maxlen);
   __syncthreads();
   if (threadIdx.x == 0) {
     f.slice_count[blockIdx.x] = (int32_t)s_kept;
     if (s_seeds) atomicAdd(f.nseed, (unsigned long long)s_seeds);
+    if (s_maxlen) atomicMax(f.nseed + 1, (unsigned long long)s_maxlen);
   }
 }
 
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void k_make_packed_keys_recs(const HitRec *
   k = (k << f.bd) | (uint32_t)r.db_sp;
   k = (k << f.bq) | (uint32_t)r.q_sp;
   k = (k << f.bl) | (uint32_t)(f.lmax - US(r.db_len));
-  k = (k << f.bl) | (uint32_t)(f.lmax - US(r.q_len));
+  if (!f.one_len) k = (k << f.bl) | (uint32_t)(f.lmax - US(r.q_len)); // (one_len: q_len = db_len in every hit of the list)
   key[i] = k;
   idx[i] = (uint32_t)i;
 }

@@ -115,6 +115,7 @@ hipError_t launch_ungapped(HitSoA hits, int64_t n, const QBatchDev &qb, const Pa
 struct PackedKeyInfo {
   int32_t qmin, lmax; // first query of the sub-batch; upper bound of q_len / db_len
   int32_t bl, bq, bd; // bits of a length, of q_sp, of db_sp
+  int32_t one_len = 0; // every hit has q_len = db_len (hits extended without gaps): the key holds the length once
 };
 hipError_t launch_make_packed_keys(const HitSoA &hits, int64_t n, const PackedKeyInfo &f, uint64_t *key, uint64_t *k_energy,
                                    uint32_t *idx, hipStream_t s);
@@ -146,7 +147,7 @@ constexpr int64_t kMaxFusedCands = 1 << 20, kMaxFusedEntries = 1 << 12;
 hipError_t launch_pair_keys(const CandDev *cands, const int64_t *pair0, int32_t ncand, int64_t npairs, const PageDev &pg, int qmin,
                             int shift, int dbits, bool wide, void *key, uint64_t *val, hipStream_t s);
 // A workgroup takes kFusePairs pairs and keeps what survives in its slice of `slices` (kFusePairs records of
-// kSliceRecBytes each), slice_count[b] of them; *nseed += seeds.  launch_collect_slices packs the slices into `out`
+// kSliceRecBytes each), slice_count[b] of them; nseed[0] += seeds, nseed[1] = max(nseed[1], length of the longest hit kept).  launch_collect_slices packs the slices into `out`
 // (slice b at slice_off[b] = the exclusive scan of the counts).
 constexpr int kFusePairs = 2048, kSliceRecBytes = 48;
 inline int64_t fused_slices(int64_t npairs) { return (npairs + kFusePairs - 1) / kFusePairs; }
