@@ -824,14 +824,14 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitRec *recs, HitSoA out, 
                                         w.idxB.as<uint32_t>(), N, 0, (unsigned)total, ctx->stream));
       PRB_HIP(launch_gather_u64(w.kE.as<uint64_t>(), w.idxB.as<uint32_t>(), w.kTmp.as<uint64_t>(), n, ctx->stream));
       PRB_HIP(hipMemsetAsync(w.pending.p, 0, 4, ctx->stream));
-      PRB_HIP(launch_fix_ties(w.kTmp2.as<uint64_t>(), w.kTmp.as<uint64_t>(), w.idxB.as<uint32_t>(), n, recs,
+      PRB_HIP(launch_fix_ties(w.kTmp2.as<uint64_t>(), w.kTmp.as<uint64_t>(), w.idxB.as<uint32_t>(), n, recs, w.idxA.as<uint32_t>(),
                               w.pending.as<int32_t>(), ctx->stream));
       int32_t too_long = 0;
       PRB_HIP(hipMemcpyAsync(&too_long, w.pending.p, 4, hipMemcpyDeviceToHost, ctx->stream));
       PRB_HIP(hipStreamSynchronize(ctx->stream));
       if (!too_long) {
-        PRB_HIP(launch_gather_recs_to_hits(recs, w.idxB.as<uint32_t>(), out, n, ctx->stream));
-        *perm_out = w.idxB.as<uint32_t>();
+        PRB_HIP(launch_gather_recs_to_hits(recs, w.idxA.as<uint32_t>(), out, n, ctx->stream));
+        *perm_out = w.idxA.as<uint32_t>();
         return PRB_OK;
       }
     }

@@ -156,8 +156,9 @@ hipError_t launch_seed_extend(const CandDev *cands, const uint64_t *vals, int64_
                               int32_t *slice_count, uint64_t *nseed, hipStream_t s);
 hipError_t launch_collect_slices(const void *slices, const int32_t *slice_count, const int64_t *slice_off, int64_t nslices, HitRec *out,
                                  hipStream_t s);
-hipError_t launch_fix_ties(const uint64_t *key_sorted, uint64_t *e_sorted, uint32_t *perm, int64_t n, const HitRec *recs,
-                           int32_t *too_long, hipStream_t s);
+// perm_out = perm with every run of equal keys put in (energy, its parts, input index) order
+hipError_t launch_fix_ties(const uint64_t *key_sorted, const uint64_t *e_sorted, const uint32_t *perm, int64_t n, const HitRec *recs,
+                           uint32_t *perm_out, int32_t *too_long, hipStream_t s);
 hipError_t launch_gather_hits_to_recs(const HitSoA &src, const uint32_t *idx, HitRec *dst, int64_t n, hipStream_t s);
 // idx == nullptr: in order
 hipError_t launch_gather_recs_to_hits(const HitRec *src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
