@@ -213,6 +213,12 @@ int prb_gather_hits(prb_comm *comm, const prb_hitset *mine, int32_t nq, const in
                     prb_hitset **out);
 int prb_hitset_gathered_queries(const prb_hitset *hs, int32_t *nranks, const int32_t **nq_of_rank,
                                 const int32_t **qlen_unmasked);
+/* The placement rule of prb_gather_hits as a pure host function (no GPU, no communicator): counts[3 * k + {0, 1, 2}] =
+ * hits, pair-array ints and queries rank k brings; bases[3 * k + j] = where rank k's share of kind j starts in the
+ * gathered arrays (k = 0 .. nranks; entry nranks = the totals).  The root receives rank k's records at bases[3k],
+ * adds bases[3k + 2] to their `query` and bases[3k + 1] / 2 to their `bp_offset`.  This is what replaces the order
+ * in which the reference's ranks append their temporary files (rna_interaction_search.cpp:426-487). */
+int prb_gather_plan(int32_t nranks, const int64_t *counts /* 3 * nranks */, int64_t *bases /* 3 * (nranks + 1) */);
 /* keep (on != 0) the packed records of later final hit sets in HBM without a communicator (tests) */
 void prb_ctx_keep_device_records(prb_ctx *ctx, int32_t on);
 

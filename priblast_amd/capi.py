@@ -89,6 +89,7 @@ SYMBOLS = {
     "prb_comm_destroy": (None, [ctypes.c_void_p]),
     "prb_gather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p, c_i32, P(ctypes.c_void_p)]),
     "prb_hitset_gathered_queries": (ctypes.c_int, [ctypes.c_void_p, P(c_i32), P(P(c_i32)), P(P(c_i32))]),
+    "prb_gather_plan": (ctypes.c_int, [c_i32, ctypes.c_void_p, ctypes.c_void_p]),
     "prb_ctx_keep_device_records": (None, [ctypes.c_void_p, c_i32]),
     "prb_write_lines": (ctypes.c_int, [ctypes.c_void_p, c_i32, P(ctypes.c_char_p), ctypes.c_void_p, ctypes.c_void_p, c_i32,
                                        c_i32, c_i64, ctypes.c_int, P(c_i64), P(c_i64)]),

@@ -192,8 +192,29 @@ void prb_comm_destroy(prb_comm *c) {
   delete c;
 }
 
-int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32_t *qlen_unmasked, int32_t root,
-                    prb_hitset **out) {
+int prb_gather_plan(int32_t nranks, const int64_t *counts, int64_t *bases) {
+  if (nranks < 1 || !counts || !bases) {
+    set_error("prb_gather_plan: bad argument");
+    return PRB_ERR_ARG;
+  }
+  for (int j = 0; j < 3; j++) bases[j] = 0;
+  for (int k = 0; k < nranks; k++)
+    for (int j = 0; j < 3; j++) {
+      if (counts[3 * k + j] < 0 || (j == 1 && (counts[3 * k + j] & 1))) {
+        set_error("prb_gather_plan: negative count, or an odd number of pair ints");
+        return PRB_ERR_ARG;
+      }
+      bases[3 * (k + 1) + j] = bases[3 * k + j] + counts[3 * k + j];
+    }
+  if (bases[3 * nranks + 2] > INT32_MAX) {
+    set_error("prb_gather_hits: more than 2^31 queries in one gather");
+    return PRB_ERR_ARG;
+  }
+  return PRB_OK;
+}
+
+static int gather_hits_impl(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32_t *qlen_unmasked, int32_t root,
+                            prb_hitset **out) {
   if (!c || !out || nq < 0 || (nq && !qlen_unmasked) || root < 0 || root >= c->nranks) {
     set_error("prb_gather_hits: bad argument");
     return PRB_ERR_ARG;
@@ -218,15 +239,13 @@ int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32
   PRB_RCCL(r.AllGather(c->meta.p, c->meta_all.p, 3, kNcclInt64, c->comm, s));
   PRB_HIP(hipMemcpyAsync(all.data(), c->meta_all.p, sizeof(int64_t) * 3 * n, hipMemcpyDeviceToHost, s));
   PRB_HIP(hipStreamSynchronize(s));
-  std::vector<int64_t> hbase((size_t)n + 1, 0), bbase((size_t)n + 1, 0), qbase((size_t)n + 1, 0);
-  for (int k = 0; k < n; k++) {
-    hbase[k + 1] = hbase[k] + all[3 * k];
-    bbase[k + 1] = bbase[k] + all[3 * k + 1];
-    qbase[k + 1] = qbase[k] + all[3 * k + 2];
-  }
-  if (qbase[n] > INT32_MAX) {
-    set_error("prb_gather_hits: more than 2^31 queries in one gather");
-    return PRB_ERR_ARG;
+  std::vector<int64_t> bases((size_t)3 * (n + 1));
+  if ((rc = prb_gather_plan(n, all.data(), bases.data()))) return rc;
+  std::vector<int64_t> hbase((size_t)n + 1), bbase((size_t)n + 1), qbase((size_t)n + 1);
+  for (int k = 0; k <= n; k++) {
+    hbase[k] = bases[3 * k];
+    bbase[k] = bases[3 * k + 1];
+    qbase[k] = bases[3 * k + 2];
   }
   // 2. point-to-point: every rank sends what it has to the root, which receives at the final offsets
   if ((rc = c->qlen.ensure(std::max<size_t>((size_t)nq * 4, 16)))) return rc;
@@ -238,11 +257,15 @@ int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32
       return rc;
   }
   PRB_RCCL(r.GroupStart());
-  if (!is_root) {
-    if (my[0]) PRB_RCCL(r.Send(mine->d_hits.b.p, (size_t)my[0] * sizeof(prb_hit), kNcclInt8, root, c->comm, s));
-    if (my[1]) PRB_RCCL(r.Send(mine->d_bp.b.p, (size_t)my[1], kNcclInt32, root, c->comm, s));
-    if (my[2]) PRB_RCCL(r.Send(c->qlen.p, (size_t)my[2], kNcclInt32, root, c->comm, s));
-  } else {
+  // (an error inside the group must not leave it open: the sends / receives are issued by a function of their own,
+  // the group is closed whatever it returns, and its error is the one reported)
+  auto issue = [&]() -> int {
+    if (!is_root) {
+      if (my[0]) PRB_RCCL(r.Send(mine->d_hits.b.p, (size_t)my[0] * sizeof(prb_hit), kNcclInt8, root, c->comm, s));
+      if (my[1]) PRB_RCCL(r.Send(mine->d_bp.b.p, (size_t)my[1], kNcclInt32, root, c->comm, s));
+      if (my[2]) PRB_RCCL(r.Send(c->qlen.p, (size_t)my[2], kNcclInt32, root, c->comm, s));
+      return PRB_OK;
+    }
     for (int k = 0; k < n; k++) {
       if (k == root) continue;
       if (all[3 * k])
@@ -250,8 +273,12 @@ int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32
       if (all[3 * k + 1]) PRB_RCCL(r.Recv(c->rx_bp.as<int32_t>() + bbase[k], (size_t)all[3 * k + 1], kNcclInt32, k, c->comm, s));
       if (all[3 * k + 2]) PRB_RCCL(r.Recv(c->rx_qlen.as<int32_t>() + qbase[k], (size_t)all[3 * k + 2], kNcclInt32, k, c->comm, s));
     }
-  }
-  PRB_RCCL(r.GroupEnd());
+    return PRB_OK;
+  };
+  rc = issue();
+  const int ge = r.GroupEnd();
+  if (rc) return rc;
+  if (ge) return rccl_fail(ge, "ncclGroupEnd");
   if (!is_root) {
     PRB_HIP(hipStreamSynchronize(s)); // `mine` may be freed by the caller right away
     return PRB_OK;
@@ -295,6 +322,17 @@ int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32
   for (int k = 0; k < n; k++) hs->g_nq_of_rank.push_back((int32_t)all[3 * k + 2]);
   *out = guard.release();
   return PRB_OK;
+}
+
+int prb_gather_hits(prb_comm *c, const prb_hitset *mine, int32_t nq, const int32_t *qlen_unmasked, int32_t root,
+                    prb_hitset **out) {
+  try {
+    return gather_hits_impl(c, mine, nq, qlen_unmasked, root, out);
+  } catch (const std::exception &e) { // (no exception leaves the C ABI)
+    if (out) *out = nullptr;
+    set_error(std::string("prb_gather_hits: ") + e.what());
+    return PRB_ERR_NOMEM;
+  }
 }
 
 int prb_hitset_gathered_queries(const prb_hitset *hs, int32_t *nranks, const int32_t **nq_of_rank, const int32_t **qlen_unmasked) {

@@ -240,8 +240,9 @@ static inline unsigned char ra_code(char ch) {
 // at out_off[i].  Sequences are processed longest first in chunks that fit the workspace budget.
 int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_t *in_off, const int32_t *lens,
                       const int64_t *out_off, int W, int delta, float *d_acc, float *d_cond) {
-  if (W < 1 || delta < 2 || W > kRaMaxSpan || W - delta > 128 || W + 2 >= RaSmallLayout::kHairpinN) {
-    set_error("unsupported (maximal span, min accessible length): need 2 <= delta, W <= 129, W - delta <= 128");
+  static_assert(kRaMaxSpan + 2 < RaSmallLayout::kHairpinN, "hairpin table covers every span");
+  if (W < 1 || delta < 2 || W > kRaMaxSpan) {
+    set_error("unsupported (maximal span -w, min accessible length -d): this build needs 1 <= w <= 255 and d >= 2");
     return PRB_ERR_ARG;
   }
   PRB_HIP(hipSetDevice(ctx->device));

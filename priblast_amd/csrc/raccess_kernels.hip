@@ -135,15 +135,27 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
-// the value the lane that owns cell `d` holds, for cells laid out d = dtop - lane over two passes (dtop = dmax, dmax - 64)
-__device__ __forceinline__ double cell_value_desc(const double (&reg)[2], int dmax, int d) {
-  const int l = dmax - d; // 0 .. 127
-  return l < 64 ? readlane_f64(reg[0], l) : readlane_f64(reg[1], l - 64);
+// Per-cell values kept in registers across the phases of a column: one double per pass over the cells (NP passes of
+// 64 lanes; NP = 2 covers maximal spans up to 127, NP = 4 up to 255).  `pass` / the index are wave-uniform.
+template <int NP>
+__device__ __forceinline__ void reg_set(double (&reg)[NP], int pass, double v) {
+#pragma unroll
+  for (int k = 0; k < NP; k++)
+    if (pass == k) reg[k] = v;
 }
-
-// the same for values laid out one per lane in ascending order over two passes (index 0 .. 127)
-__device__ __forceinline__ double lane_value_asc(const double (&reg)[2], int idx) {
-  return idx < 64 ? readlane_f64(reg[0], idx) : readlane_f64(reg[1], idx - 64);
+// element idx (0 .. 64 * NP - 1) of values laid out one per lane, pass after pass
+template <int NP>
+__device__ __forceinline__ double lane_value_asc(const double (&reg)[NP], int idx) {
+  double r = readlane_f64(reg[0], idx & 63);
+#pragma unroll
+  for (int k = 1; k < NP; k++)
+    if ((idx >> 6) == k) r = readlane_f64(reg[k], idx & 63);
+  return r;
+}
+// the value the lane that owns cell `d` holds, for cells laid out d = dtop - lane (dtop = dmax, dmax - 64, ...)
+template <int NP>
+__device__ __forceinline__ double cell_value_desc(const double (&reg)[NP], int dmax, int d) {
+  return lane_value_asc<NP>(reg, dmax - d);
 }
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -156,6 +168,7 @@ __global__ void k_fill(double *p, int64_t n, double value) {
 }
 
 // ------------------------------------------------------------------------------ inside
+template <int NP>
 __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
   __shared__ RowMasks rowmasks[kWavesPerBlock];
@@ -188,7 +201,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
     // phase 1: Alpha_stem (raccess.cpp:102-129) and Alpha_multi2 (:145-162): both need only
     // column j-1 and the cell itself.  Also, per cell, the term it contributes to Alpha_outer[j] (:230-241),
     // kept in a register for the chain of phase 3.
-    double to_reg[2] = {kNegInf, kNegInf}, mb_reg[2] = {kNegInf, kNegInf};
+    double to_reg[NP], mb_reg[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) to_reg[k] = mb_reg[k] = kNegInf;
     int pass = 0;
     for (int dtop = dmax; dtop >= kTurn; dtop -= kWave, pass++) {
       const int d = dtop - lane;
@@ -220,8 +235,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
         temp = stem + MLintern + dng;
         flag = true;
         const double x = stem + dng; // (:235-236)
-        if (pass == 0) to_reg[0] = x + ao[i];
-        else to_reg[1] = x + ao[i];
+        reg_set<NP>(to_reg, pass, x + ao[i]);
       }
       const double prev = EM(a_multi2, i, j - 1);
       double m2;
@@ -263,8 +277,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
       }
       if (!cell) continue;
       const double mb = flag ? temp : kNegInf;
-      if (pass == 0) mb_reg[0] = mb;
-      else mb_reg[1] = mb;
+      reg_set<NP>(mb_reg, pass, mb);
       EM(a_multibif, i, j) = mb;
       const double m2 = EM(a_multi2, i, j);
       double m1;
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
       double acc = l0 ? kNegInf : ao[j - 1]; // lane 0: Alpha_multi of the previous cell (none before d = 3); lane 1: the running sum
       for (int k = 0; k + kTurn <= dmax; k++) {
         const int d0 = kTurn + k, d1 = dmax - k;
-        const double mb = cell_value_desc(mb_reg, dmax, d0), to = cell_value_desc(to_reg, dmax, d1);
+        const double mb = cell_value_desc<NP>(mb_reg, dmax, d0), to = cell_value_desc<NP>(to_reg, dmax, d1);
         if (lane < 2) {
           const double term = l0 ? mb : to;
           const double base = l0 ? acc + MLbase : acc;
@@ -454,6 +467,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
 }
 
 // ----------------------------------------------------------------------------- outside
+template <int NP>
 __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
   __shared__ RowMasks rowmasks[kWavesPerBlock];
@@ -502,7 +516,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
     if (use_masks && lane == 0) rowmask_clear(rm, q - W); // the row whose first cell comes in column q - 1 (spans >= W never exist)
     // Also, in registers for the chains of phase B: per cell the term it contributes to Beta_multi (:296-300), and
     // - one per lane, p' = q + lane (+ 64) - the terms of Beta_outer[q - 1] (:262-269).
-    double xb_reg[2] = {kNegInf, kNegInf}, tob_reg[2] = {kNegInf, kNegInf};
+    double xb_reg[NP], tob_reg[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) xb_reg[k] = tob_reg[k] = kNegInf;
     const int pend_o = imin(q + W, L); // Beta_outer[q - 1] sums p' = q .. pend_o
     {
       int pass = 0;
@@ -518,12 +534,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
             const int tt = ra_rtype(ra_bp(lds, s[p], s[q + 1]));
             const double x = se + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + s[p + 1]] +
                              lds.small[SL::kDangle5 + tt * 5 + s[q]];
-            if (pass == 0) xb_reg[0] = x;
-            else xb_reg[1] = x;
+            reg_set<NP>(xb_reg, pass, x);
           }
         }
       }
-      for (pass = 0; pass < 2; pass++) {
+      for (pass = 0; pass < NP; pass++) {
         const int pp = q + lane + 64 * pass;
         if (pp > pend_o) continue;
         const int i = q - 1;
@@ -531,8 +546,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
         if (st != kNegInf) {
           const int type = ra_bp(lds, s[i + 1], s[pp]);
           const double x = st + dangle_energy(lds, v, type, i, pp);
-          if (pass == 0) tob_reg[0] = x + bo[pp];
-          else tob_reg[1] = x + bo[pp];
+          reg_set<NP>(tob_reg, pass, x + bo[pp]);
         }
       }
     }
@@ -547,8 +561,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
       double acc = l0 ? kNegInf : bo[q]; // lane 0: Beta_multi of the previous cell; lane 1: the running sum
       for (int k = 0; k < imax(k0n, k1n); k++) {
         const int d0 = dmax - k;
-        const double xb = k < k0n ? lane_value_asc(xb_reg, d0 - kTurn) : kNegInf;
-        const double to = k < k1n ? lane_value_asc(tob_reg, k) : kNegInf;
+        const double xb = k < k0n ? lane_value_asc<NP>(xb_reg, d0 - kTurn) : kNegInf;
+        const double to = k < k1n ? lane_value_asc<NP>(tob_reg, k) : kNegInf;
         if (lane < 2) {
           const double term = l0 ? xb : to;
           const double base = l0 ? acc + MLbase : acc;
@@ -793,17 +807,34 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
 // Ordered scatter of every interior-loop term into the positions it makes accessible
 // (raccess.cpp:626-665 / :695-752).  The sums per position k are sequential in the
 // reference, so tuples are applied one at a time in (i, j, p, q) order; the lanes own the
-// positions (k mod 64, two slots for windows up to 128), so one tuple updates all its
+// positions (k mod 64, NS slots for windows up to 64 * NS positions), so one tuple updates all its
 // positions in one predicated instruction.
-template <bool kLogSum>
+template <int NS>
+__device__ __forceinline__ double slot_get(const double (&a)[NS], int sl) {
+  double r = a[0];
+#pragma unroll
+  for (int t = 1; t < NS; t++)
+    if (sl == t) r = a[t];
+  return r;
+}
+template <int NS>
+__device__ __forceinline__ void slot_put(double (&a)[NS], int sl, double v) {
+#pragma unroll
+  for (int t = 0; t < NS; t++)
+    if (sl == t) a[t] = v;
+}
+
+template <bool kLogSum, int NS>
 __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v, int delta, int lane) {
   const int L = v.L, W = v.W, S = v.S;
   const unsigned char *s = v.s;
   const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
   double *bp = v.v(V_BP), *cbp = v.v(V_CBP), *bfl = v.v(V_BFLAG), *cfl = v.v(V_CFLAG);
-  // accumulators of position k live on lane k & 63, slot (k >> 6) & 1
-  double accb0 = 0, accb1 = 0, accc0 = 0, accc1 = 0;
-  bool fb0 = false, fb1 = false, fc0 = false, fc1 = false;
+  // accumulators of position k live on lane k & 63, slot (k >> 6) & (NS - 1); "has a term" flags: one bit per slot
+  double accb[NS], accc[NS];
+#pragma unroll
+  for (int t = 0; t < NS; t++) accb[t] = accc[t] = 0;
+  unsigned fb = 0, fc = 0;
 
   for (int i = 1; i < L - kTurn - 2; i++) {
     const int kb = i + 1; // smallest position this and later i can touch
@@ -843,27 +874,27 @@ __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v,
           const int tq = __shfl(q, src);
           const int kr0 = tq + 1, kr1 = j - delta; // right range [q+1, j-delta]
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
+          for (int h = 0; h < NS; h++) {
             const int k = kb + ((lane - kb) & 63) + 64 * h;
             const bool inl = k <= kl1; // k >= kb = i+1 always
             const bool inr = k >= kr0 && k <= kr1;
             if (inl || inr) {
               const bool last = inl ? k == kl1 : k == kr1;
-              const bool sl = (k >> 6) & 1;
+              const int sl = (k >> 6) & (NS - 1);
               if (!kLogSum) {
-                if (last) { if (sl) accb1 += tv; else accb0 += tv; }
-                else { if (sl) accc1 += tv; else accc0 += tv; }
+                if (last) slot_put<NS>(accb, sl, slot_get<NS>(accb, sl) + tv);
+                else slot_put<NS>(accc, sl, slot_get<NS>(accc, sl) + tv);
               } else {
                 if (last) {
-                  const double cur = sl ? accb1 : accb0;
-                  const bool f = sl ? fb1 : fb0;
-                  const double nv = f ? ra_lse(lds, cur, tv) : tv;
-                  if (sl) { accb1 = nv; fb1 = true; } else { accb0 = nv; fb0 = true; }
+                  const double cur = slot_get<NS>(accb, sl);
+                  const double nv = ((fb >> sl) & 1) ? ra_lse(lds, cur, tv) : tv;
+                  slot_put<NS>(accb, sl, nv);
+                  fb |= 1u << sl;
                 } else {
-                  const double cur = sl ? accc1 : accc0;
-                  const bool f = sl ? fc1 : fc0;
-                  const double nv = f ? ra_lse(lds, cur, tv) : tv;
-                  if (sl) { accc1 = nv; fc1 = true; } else { accc0 = nv; fc0 = true; }
+                  const double cur = slot_get<NS>(accc, sl);
+                  const double nv = ((fc >> sl) & 1) ? ra_lse(lds, cur, tv) : tv;
+                  slot_put<NS>(accc, sl, nv);
+                  fc |= 1u << sl;
                 }
               }
             }
@@ -873,13 +904,15 @@ __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v,
     }
     // position k = i+1 receives nothing from later i: store it and recycle the slot
     if ((kb & 63) == lane) {
-      const bool sl = (kb >> 6) & 1;
-      bp[kb - 1] = sl ? accb1 : accb0;
-      cbp[kb - 1] = sl ? accc1 : accc0;
-      bfl[kb - 1] = (sl ? fb1 : fb0) ? 1.0 : 0.0;
-      cfl[kb - 1] = (sl ? fc1 : fc0) ? 1.0 : 0.0;
-      if (sl) { accb1 = 0; accc1 = 0; fb1 = false; fc1 = false; }
-      else { accb0 = 0; accc0 = 0; fb0 = false; fc0 = false; }
+      const int sl = (kb >> 6) & (NS - 1);
+      bp[kb - 1] = slot_get<NS>(accb, sl);
+      cbp[kb - 1] = slot_get<NS>(accc, sl);
+      bfl[kb - 1] = ((fb >> sl) & 1) ? 1.0 : 0.0;
+      cfl[kb - 1] = ((fc >> sl) & 1) ? 1.0 : 0.0;
+      slot_put<NS>(accb, sl, 0.0);
+      slot_put<NS>(accc, sl, 0.0);
+      fb &= ~(1u << sl);
+      fc &= ~(1u << sl);
     }
   }
   // positions beyond the last i keep their zero-initialised value: every position that
@@ -887,13 +920,15 @@ __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v,
   // except those with k - 1 >= L - 5; flush what the last windows left behind.
   for (int k = imax(2, L - kTurn - 2 + 1); k <= L; k++) {
     if ((k & 63) == lane) {
-      const bool sl = (k >> 6) & 1;
-      bp[k - 1] = sl ? accb1 : accb0;
-      cbp[k - 1] = sl ? accc1 : accc0;
-      bfl[k - 1] = (sl ? fb1 : fb0) ? 1.0 : 0.0;
-      cfl[k - 1] = (sl ? fc1 : fc0) ? 1.0 : 0.0;
-      if (sl) { accb1 = 0; accc1 = 0; fb1 = false; fc1 = false; }
-      else { accb0 = 0; accc0 = 0; fb0 = false; fc0 = false; }
+      const int sl = (k >> 6) & (NS - 1);
+      bp[k - 1] = slot_get<NS>(accb, sl);
+      cbp[k - 1] = slot_get<NS>(accc, sl);
+      bfl[k - 1] = ((fb >> sl) & 1) ? 1.0 : 0.0;
+      cfl[k - 1] = ((fc >> sl) & 1) ? 1.0 : 0.0;
+      slot_put<NS>(accb, sl, 0.0);
+      slot_put<NS>(accc, sl, 0.0);
+      fb &= ~(1u << sl);
+      fc &= ~(1u << sl);
     }
   }
 }
@@ -909,24 +944,25 @@ __device__ void biloop_run(const RaLds &lds, const RaConst &c, const SeqView &v,
 // finalisation then takes the same branches as with the true sums) and returns false when some
 // position needs its true sum, in which case the caller runs the ordered pass.  For random RNA
 // of 1 kb (log Z ~ 270) every position is decided here.
+template <int NS>
 __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqView &v, int delta, int lane) {
   const int L = v.L, W = v.W, S = v.S;
   const unsigned char *s = v.s;
   const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
   double *bp = v.v(V_BP), *cbp = v.v(V_CBP);
-  // flags of position k live on lane k & 63, slot (k >> 6) & 1: bit 0 b-big, 1 b-nonzero, 2 c-big, 3 c-nonzero
-  unsigned f0 = 0, f1 = 0;
+  // flags of position k live on lane k & 63, in nibble (k >> 6) & (NS - 1) of one word: bit 0 b-big, 1 b-nonzero,
+  // 2 c-big, 3 c-nonzero
+  unsigned fl = 0;
   bool undecided = false;
   auto flush = [&](int k) {
     if ((k & 63) == lane) {
-      const bool sl = (k >> 6) & 1;
-      const unsigned f = sl ? f1 : f0;
+      const int sl = (k >> 6) & (NS - 1);
+      const unsigned f = (fl >> (4 * sl)) & 15u;
       const bool bbig = f & 1, bnz = f & 2, cbig = f & 4, cnz = f & 8;
       if (!((cbig || !cnz) && (cbig || bbig || !bnz))) undecided = true;
       bp[k - 1] = bnz ? __builtin_huge_val() : 0.0;
       cbp[k - 1] = cnz ? __builtin_huge_val() : 0.0;
-      if (sl) f1 = 0;
-      else f0 = 0;
+      fl &= ~(15u << (4 * sl));
     }
   };
   for (int i = 1; i < L - kTurn - 2; i++) {
@@ -1002,7 +1038,7 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
         // the positions: left ranges end at p - delta = i + 1 + u1 - delta, right ranges at j - delta
         const int qbase = j - 1 - m;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NS; h++) {
           const int k = kb + ((lane - kb) & 63) + 64 * h;
           unsigned add = 0;
           const int ustar = k - (i + 1 - delta); // the row whose left range ends at k
@@ -1020,8 +1056,7 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
               if (col_nz & below) add |= (k == kr1 ? 2u : 8u) | ((col_big & below) ? (k == kr1 ? 1u : 4u) : 0u);
             }
           }
-          if ((k >> 6) & 1) f1 |= add;
-          else f0 |= add;
+          fl |= add << (4 * ((k >> 6) & (NS - 1)));
         }
       }
     }
@@ -1031,6 +1066,7 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
   return __ballot(undecided) == 0;
 }
 
+template <int NS>
 __global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
   ra_load_lds(lds, c);
@@ -1041,9 +1077,9 @@ __global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
   const double pf = v.v(V_AO)[v.L];
   if (pf >= -690 && pf <= 690) { // raccess.cpp:500-507
     // large log Z: nearly always decided by the classification alone
-    if (pf < 120.0 || !biloop_classify(lds, c, v, b.delta, lane)) biloop_run<false>(lds, c, v, b.delta, lane);
+    if (pf < 120.0 || !biloop_classify<NS>(lds, c, v, b.delta, lane)) biloop_run<false, NS>(lds, c, v, b.delta, lane);
   } else {
-    biloop_run<true>(lds, c, v, b.delta, lane);
+    biloop_run<true, NS>(lds, c, v, b.delta, lane);
   }
 }
 
@@ -1176,9 +1212,17 @@ hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int
   hipLaunchKernelGGL(k_fill, dim3(fill_blocks), dim3(256), 0, stream, b.band, band_elems, kNegInf);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, stream, b.vec, vec_elems, 0.0);
   const int blocks = (b.nseq + kWavesPerBlock - 1) / kWavesPerBlock;
-  hipLaunchKernelGGL(k_inside, dim3(blocks), dim3(kBlock), 0, stream, b, c);
-  hipLaunchKernelGGL(k_outside, dim3(blocks), dim3(kBlock), 0, stream, b, c);
-  hipLaunchKernelGGL(k_biloop, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  // cells of a column (spans 3 .. W + 1) and terms of Beta_outer (W + 1) per pass of 64 lanes: two passes up to a
+  // maximal span of 127 (the default is 70), four up to kRaMaxSpan
+  if (b.W + 1 <= 128) {
+    hipLaunchKernelGGL(k_inside<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_outside<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_biloop<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  } else {
+    hipLaunchKernelGGL(k_inside<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_outside<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_biloop<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  }
   hipLaunchKernelGGL(k_access, dim3(blocks), dim3(kBlock), 0, stream, b, c);
   return hipGetLastError();
 }

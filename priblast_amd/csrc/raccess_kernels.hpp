@@ -20,7 +20,7 @@ struct RaSeqDesc {
 
 constexpr int kRaBands = 13;
 constexpr int kRaVecs = 8;
-constexpr int kRaMaxSpan = 129; // W - delta <= 128 (two accumulator slots per lane in k_biloop)
+constexpr int kRaMaxSpan = 255; // cells of a column / positions of a window: at most four passes of 64 lanes (raccess_kernels.hip)
 
 struct RaBatch {
   const RaSeqDesc *desc;

@@ -14,6 +14,9 @@ compiled reference produced for them (strict build: -ffp-contract=off, SURVEY.md
   mix_*.fa, mixdb.*.gz, mix_ris_s{0,1}.out, mix.stg.gz
                         mixed-length case: N / lowercase, 3 DB pages (-c 10)
   c1_q.sa               encoder + suffix array goldens             (ref_harness sa)
+  widew.fa, widew_w<W>d<delta>.racc
+                        Raccess beyond the default band: maximal spans 100, 129, 150 and 200 (spans wider than
+                        the 64 / 128 cells the HIP kernels' default mappings cover), several window lengths
   quirk_*.fa, quirkdb.*.gz, quirk_ris_s{0,1}.out, quirk.stg.gz
                         designed duplexes with a bulge next to the seed: the FIRST post-ungapped hit of a
                         query is gapped-extended and survives the final filter, so it keeps the unsorted
@@ -76,6 +79,21 @@ def corpus():
     recs.append(("withN_lower", "".join(s)))
     recs.append(("dna_T", "".join(rng.choice("ACGT") for _ in range(150))))
     recs.append(("allN", "N" * 40))
+    return recs
+
+
+WIDE_W = [(100, 5), (129, 5), (129, 2), (150, 5), (200, 4)]
+
+
+def widew_corpus():
+    """A subset of corpus() (same sequences: same generator, same order) + one GC-rich 700-mer whose log Z sits in
+    the linear bulge / interior branch at every span."""
+    d = dict(corpus())
+    recs = [(k, d[k]) for k in ("len4", "len60", "len72", "len200", "len330", "len1000", "hairpins", "withN_lower", "polyGC")]
+    rng = random.Random(17)
+    recs.append(("len150", "".join(rng.choice("ACGU") for _ in range(150))))
+    recs.append(("gc700", "".join(rng.choice("GGGCCCAU") for _ in range(700))))
+    recs.append(("gc1500", "".join(rng.choice("GGGCCCAU") for _ in range(1500))))
     return recs
 
 
@@ -152,6 +170,11 @@ def main():
         # a second (W, delta) so the band geometry is not hard-wired to the defaults
         run(harness, "raccess", os.path.join(HERE, "c1_q.fa"), "40", "7", os.path.join(HERE, "c1_q_w40d7.racc"))
         run(harness, "sa", os.path.join(HERE, "c1_q.fa"), "0", os.path.join(HERE, "c1_q.sa"))
+    if not only or "widew" in only:
+        gen_synthetic.write_fasta(os.path.join(HERE, "widew.fa"), widew_corpus())
+        for W, delta in WIDE_W:
+            run(harness, "raccess", os.path.join(HERE, "widew.fa"), str(W), str(delta),
+                os.path.join(HERE, f"widew_w{W}d{delta}.racc"))
     cases = [("c1", "c1_q.fa", "c1_db.fa", []), ("mix", "mix_q.fa", "mix_db.fa", ["-c", "10"]),
              ("quirk", "quirk_q.fa", "quirk_db.fa", ["-c", "2"])]
     if only:

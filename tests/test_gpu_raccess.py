@@ -23,12 +23,17 @@ def ctx():
     c.close()
 
 
-def test_dp_tables_match_oracle(ctx, oracle):
-    """Every DP table of one sequence, cell by cell (diagnostics entry point)."""
+@pytest.mark.parametrize("W,delta", [(70, 5), (100, 5), (127, 3), (128, 5), (150, 5), (255, 2)])
+def test_dp_tables_match_oracle(ctx, oracle, W, delta):
+    """Every DP table of one sequence, cell by cell (diagnostics entry point).  Maximal spans beyond 96 leave the
+    row-mask form of the two big folds (raccess_kernels.hip: use_masks), beyond 127 the two-pass cell mapping."""
     names, seqs = refdump.read_fasta(os.path.join(GOLDEN, "c1_q.fa"))
-    for s in (seqs[0][:40], seqs[1], "GGGGGCCAAAAGGCCCCCAUAU" * 6):
-        acc, cond, t = ctx.accessibility_tables(s, 70, 5)
-        oa, oc, ot = oracle.raccess(s, 70, 5, debug=True)
+    cases = (seqs[0][:40], seqs[1], "GGGGGCCAAAAGGCCCCCAUAU" * 6)
+    if W > 70:
+        cases = (seqs[1] + seqs[2], "GGGGGCCAAAAGGCCCCCAUAU" * 14)
+    for s in cases:
+        acc, cond, t = ctx.accessibility_tables(s, W, delta)
+        oa, oc, ot = oracle.raccess(s, W, delta, debug=True)
         bad = []
         for k in ("alpha_stem", "alpha_multi2", "alpha_multibif", "alpha_multi1", "alpha_multi", "alpha_stemend",
                   "alpha_outer", "beta_outer", "beta_stemend", "beta_multi", "beta_multi1", "beta_multibif",
@@ -42,7 +47,10 @@ def test_dp_tables_match_oracle(ctx, oracle):
         assert np.array_equal(bits(cond), bits(oc))
 
 
-@pytest.mark.parametrize("fa,racc", [("corpus.fa", "corpus.racc"), ("c1_q.fa", "c1_q_w40d7.racc")])
+WIDE = [("widew.fa", f"widew_w{W}d{d}.racc") for W, d in ((100, 5), (129, 5), (129, 2), (150, 5), (200, 4))]
+
+
+@pytest.mark.parametrize("fa,racc", [("corpus.fa", "corpus.racc"), ("c1_q.fa", "c1_q_w40d7.racc")] + WIDE)
 def test_golden_accessibilities_bit_exact(ctx, fa, racc):
     names, seqs = refdump.read_fasta(os.path.join(GOLDEN, fa))
     g = refdump.read_raccess(os.path.join(GOLDEN, racc))
@@ -50,6 +58,14 @@ def test_golden_accessibilities_bit_exact(ctx, fa, racc):
     for name, (acc, cond), rec in zip(names, res, g["seqs"]):
         assert np.array_equal(bits(acc), bits(rec["acc"])), name
         assert np.array_equal(bits(cond), bits(rec["cond"])), name
+
+
+def test_spans_outside_the_supported_range_are_refused(ctx):
+    """The kernels map the cells of a column onto at most four passes of 64 lanes: -w beyond 255 is an error, not a
+    wrong answer (INTEGRATION.md lists the limit)."""
+    from priblast_amd import capi
+    with pytest.raises(capi.PrbError):
+        ctx.accessibility(["ACGU" * 100], 256, 5)
 
 
 def test_batch_order_and_chunking_do_not_matter(ctx, oracle):

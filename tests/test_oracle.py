@@ -35,7 +35,10 @@ def test_fmath_tables_and_probes(oracle):
     assert L.orc_expd(-708.4) == 0.0
 
 
-@pytest.mark.parametrize("fa,racc", [("corpus.fa", "corpus.racc"), ("c1_q.fa", "c1_q_w40d7.racc")])
+WIDE = [("widew.fa", f"widew_w{W}d{d}.racc") for W, d in ((100, 5), (129, 5), (129, 2), (150, 5), (200, 4))]
+
+
+@pytest.mark.parametrize("fa,racc", [("corpus.fa", "corpus.racc"), ("c1_q.fa", "c1_q_w40d7.racc")] + WIDE)
 def test_raccess_bit_exact(oracle, fa, racc):
     names, seqs = refdump.read_fasta(os.path.join(GOLDEN, fa))
     g = refdump.read_raccess(os.path.join(GOLDEN, racc))
