@@ -2,7 +2,10 @@
 """Benchmark of the `ris` hot path on MI355X (BASELINE.json metric: query RNAs/sec in `ris`).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: one process per GPU.  Under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+  bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) this process is one rank;
+  started plainly with --gpus N it starts the N ranks itself (fresh child processes, before anything here has
+  touched the GPU) on 127.0.0.1 and passes rank 0's JSON line through.
 
 Workload (config.workload): BASELINE.json configs[2], the largest single-GPU configuration - synthetic
 i.i.d. uniform A/C/G/U, 2 kb queries (seed 2) against the 50,000 x 2 kb database (seed 1, 100 M
@@ -213,12 +216,50 @@ def cpu_baseline(a, ctx, workdir, qnames, qseqs, log):
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N children of this very command, one per GPU, with the
+    environment torch.distributed.run would give them.  Nothing in this process has initialised the GPU (torch is
+    not even imported yet); rank 0's stdout is ours, so its one JSON line is this command's output."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:  # one rank failed: the others would wait for it in a collective
+                    rc = code
+                    for o in pending:
+                        o.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
 
     def log(msg):
         if rank == 0:
@@ -243,10 +284,17 @@ def main():
     os.environ.setdefault("PRB_HOST_THREADS", str(max(2, min(32, host_cores() // (2 * max(world, 1))))))
     if world > 1 and rank == 0:  # rank 0 alone writes the lines, for all ranks: half of the CPUs for that
         os.environ.setdefault("PRB_FORMAT_THREADS", str(max(2, min(32, host_cores() // 2))))
+    # Rehearsal of the N > 1 path on a box with ONE GPU (tests/test_gpu_multirank.py): BENCH_SHARE_GPU=1 puts every rank on
+    # device 0, BENCH_DIST_BACKEND=gloo carries torch.distributed's barrier / reductions (RCCL refuses two ranks on one
+    # device; the hit gather then needs PRB_RCCL_LIB = the tests' file transport).  Never set for a measurement.
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    tdev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local)
     multi = world > 1 or a.force_comm
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
     elif a.force_comm:
         os.makedirs(a.workdir, exist_ok=True)
         store = os.path.join(a.workdir, f"rdv_{os.getpid()}")
@@ -286,7 +334,7 @@ def main():
     shape = {(5000, 1000): "BASELINE configs[1] shape", (50000, 2000): "BASELINE configs[2]: the full 50,000 x 2 kb database, a contiguous sample of its 50,000 queries",
              (32, 200): "BASELINE configs[0] shape"}.get((a.db_seqs, a.length), "not a BASELINE config")
     devnull = os.open(os.devnull, os.O_WRONLY)
-    comm = pdist.NativeComm(ctx, rank, world) if multi else None
+    comm = pdist.NativeComm(ctx, rank, world, tdev) if multi else None
 
     wall = collections.defaultdict(float)
     sink = {"lines": 0, "bytes": 0}
@@ -405,10 +453,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t
     if multi:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cc = torch.tensor(counts, device="cuda", dtype=torch.int64)
+        cc = torch.tensor(counts, device=tdev, dtype=torch.int64)
         dist.all_reduce(cc)
         allc = [int(x) for x in cc.tolist()]
     else:
@@ -452,8 +500,8 @@ def main():
                          "units_per_launch": gap_units / max(gap_launch, 1), "bytes_per_unit": GAPPED_BYTES_PER_HIT,
                          "ns_per_unit": gap_ms * 1e6 / max(gap_units, 1)},
         }
-        if world == 1:
-            res["cpu_baseline"] = cpu_baseline(a, ctx, a.workdir, qnames, qseqs, log)
+        # (N > 1: the other ranks wait at the closing barrier meanwhile; the sample is bounded to ~20 s of wall time)
+        res["cpu_baseline"] = cpu_baseline(a, ctx, a.workdir, qnames, qseqs, log)
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if state["prep"] is not None and state["prep"].qb is not None:
         state["prep"].qb.close()

@@ -201,7 +201,7 @@ int prb_write_lines(const prb_db *db, int32_t nq, const char *const *qnames, con
  * prb_hitset_gathered_queries gives every rank's batch size and the unmasked lengths of all the
  * queries in the same order.  Elsewhere *out = NULL.  A rank without a batch in this round passes mine = NULL,
  * nq = 0.  The gathered hit set borrows a pinned buffer of the communicator until it is
- * freed with prb_hitset_free (from any thread; before prb_comm_destroy).  The gather works on a stream of
+ * freed with prb_hitset_free (from any thread; the buffer outlives prb_comm_destroy if it has to).  The gather works on a stream of
  * its own, so one host thread may gather (and print) batch k while another one searches batch k + 1 on the
  * context - as long as every rank issues its gathers in the same order. */
 typedef struct prb_comm prb_comm;

@@ -384,7 +384,9 @@ class Comm:
         nq_of = np.ctypeslib.as_array(pn, (n.value,)).copy()
         total = int(nq_of.sum())
         qall = np.ctypeslib.as_array(pq, (total,)).copy() if total else np.zeros(0, np.int32)
-        return HitSet(out), nq_of, qall
+        g = HitSet(out)
+        g._owner.comm = self  # (not needed by the library - the pinned buffer is shared with the hit set - but it keeps the
+        return g, nq_of, qall  #  order of destruction the plain one: hit sets first)
 
 
 def write_lines(db, qnames, qlen_unmasked, pages, output_style=0, id0=0, fd=-1):

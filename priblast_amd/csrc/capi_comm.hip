@@ -100,20 +100,17 @@ __global__ __launch_bounds__(256) void k_rebase_hits(prb_hit *h, int64_t n, int3
 
 using namespace prb;
 
-struct prb_comm {
-  prb_ctx *ctx = nullptr;
-  void *comm = nullptr;
-  int32_t nranks = 1, rank = 0;
-  hipStream_t stream = nullptr; // the gather's own stream: it may run (from another host thread) beside the next search
-  DevBuf meta, meta_all, qlen, rx_hits, rx_bp, rx_qlen;
-  // pinned slots: a gathered hit set lives in one until it is freed (possibly by another thread)
+// Pinned slots: a gathered hit set lives in one until it is freed (possibly by another thread, possibly after its
+// communicator is gone: the pool belongs to the communicator AND to every hit set that borrows from it).
+struct SlotPool {
   struct Slot {
     PinnedBuf hits, bp;
     bool busy = false;
   };
   std::vector<std::unique_ptr<Slot>> slots;
   std::mutex mu;
-  int take_slot() {
+  int device = 0;
+  int take() {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i < slots.size(); i++)
       if (!slots[i]->busy) {
@@ -124,11 +121,31 @@ struct prb_comm {
     slots.back()->busy = true;
     return (int)slots.size() - 1;
   }
-  static void give_back(void *owner, int slot) {
-    auto *c = static_cast<prb_comm *>(owner);
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->slots[(size_t)slot]->busy = false;
+  ~SlotPool() {
+    (void)hipSetDevice(device);
+    for (auto &sl : slots) {
+      sl->hits.release();
+      sl->bp.release();
+    }
   }
+  // prb_hitset::ext_release: `owner` is the hit set's own reference to the pool
+  static void give_back(void *owner, int slot) {
+    auto *ref = static_cast<std::shared_ptr<SlotPool> *>(owner);
+    {
+      std::lock_guard<std::mutex> lk((*ref)->mu);
+      (*ref)->slots[(size_t)slot]->busy = false;
+    }
+    delete ref; // (the last reference frees the pinned buffers)
+  }
+};
+
+struct prb_comm {
+  prb_ctx *ctx = nullptr;
+  void *comm = nullptr;
+  int32_t nranks = 1, rank = 0;
+  hipStream_t stream = nullptr; // the gather's own stream: it may run (from another host thread) beside the next search
+  DevBuf meta, meta_all, qlen, rx_hits, rx_bp, rx_qlen;
+  std::shared_ptr<SlotPool> pool = std::make_shared<SlotPool>();
 };
 
 extern "C" {
@@ -162,6 +179,7 @@ int prb_comm_create(prb_ctx *ctx, int32_t nranks, int32_t rank, const char id[PR
   c->ctx = ctx;
   c->nranks = nranks;
   c->rank = rank;
+  c->pool->device = ctx->device;
   UniqueId u;
   std::memcpy(u.internal, id, PRB_COMM_ID_BYTES);
   if (hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); e != hipSuccess) {
@@ -185,11 +203,7 @@ void prb_comm_destroy(prb_comm *c) {
   if (c->comm) (void)rccl().CommDestroy(c->comm);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (DevBuf *b : {&c->meta, &c->meta_all, &c->qlen, &c->rx_hits, &c->rx_bp, &c->rx_qlen}) b->release();
-  for (auto &sl : c->slots) {
-    sl->hits.release();
-    sl->bp.release();
-  }
-  delete c;
+  delete c; // (the pinned slots go with the last gathered hit set that still borrows one)
 }
 
 int prb_gather_plan(int32_t nranks, const int64_t *counts, int64_t *bases) {
@@ -296,12 +310,12 @@ static int gather_hits_impl(prb_comm *c, const prb_hitset *mine, int32_t nq, con
     PRB_HIP(hipGetLastError());
   }
   // 4. to pinned host memory, once
-  const int slot = c->take_slot();
-  prb_comm::Slot &sl = *c->slots[(size_t)slot];
+  const int slot = c->pool->take();
+  SlotPool::Slot &sl = *c->pool->slots[(size_t)slot];
   auto *hs = new prb_hitset(); // (owns the slot from here on: freed on every error path below)
   hs->device = ctx->device;
-  hs->ext_release = &prb_comm::give_back;
-  hs->ext_owner = c;
+  hs->ext_release = &SlotPool::give_back;
+  hs->ext_owner = new std::shared_ptr<SlotPool>(c->pool);
   hs->ext_slot = slot;
   std::unique_ptr<prb_hitset> guard(hs);
   if ((rc = sl.hits.ensure(std::max<size_t>((size_t)hbase[n] * sizeof(prb_hit), 16))) ||

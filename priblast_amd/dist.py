@@ -32,9 +32,9 @@ class NativeComm:
     """The RCCL communicator of the final hit gather; torch.distributed (already initialised, backend
     nccl = RCCL) only broadcasts the communicator id."""
 
-    def __init__(self, ctx, rank, world):
+    def __init__(self, ctx, rank, world, device="cuda"):
         uid = capi.Comm.unique_id() if rank == 0 else bytes(capi.Comm.ID_BYTES)
-        t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=device)
         dist.broadcast(t, 0)
         self.comm = capi.Comm(ctx, world, rank, bytes(t.cpu().tolist()))
         self.rank, self.world = rank, world

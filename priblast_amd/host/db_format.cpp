@@ -106,11 +106,16 @@ std::string read_db(const std::string &prefix, DbHeader &hdr, std::vector<DbPage
         auto &h = pass == 0 ? pg.start_hash[i] : pg.end_hash[i];
         h.resize(n);
         if (!ind.rd(h.data(), 4 * n)) return "Error: truncated " + prefix + ".ind";
-        // an interval of the suffix array, or the empty one stored as (1, 0)
-        for (int32_t v : h)
-          if (v < 0 || v > nsa) return "Error: corrupt " + prefix + ".ind (k-mer interval out of range)";
       }
     }
+    // every k-mer's [start, end] is an inclusive interval of the suffix array (the seed DFS and the kernels index
+    // sa[start .. end]), or the empty one, stored as (1, 0)
+    for (int i = 0; i < hdr.hash_size; i++)
+      for (size_t k = 0; k < pg.start_hash[i].size(); k++) {
+        const int32_t sp = pg.start_hash[i][k], ep = pg.end_hash[i][k];
+        const bool empty = sp == 1 && ep == 0;
+        if (!empty && (sp < 0 || ep >= nsa || sp > ep)) return "Error: corrupt " + prefix + ".ind (k-mer interval out of range)";
+      }
   }
   return "";
 }

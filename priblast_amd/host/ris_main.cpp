@@ -28,6 +28,7 @@
 #include <numeric>
 #include <condition_variable>
 #include <map>
+#include <cctype>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -297,32 +298,101 @@ void search_batch(Worker &w, const Args &a, Prepared &p, int npages, std::vector
   p.qb = nullptr;
 }
 
-// The RCCL id of a multi-process run: rank 0 writes it to `path` (atomically), the others wait for it.
-void exchange_comm_id(const std::string &path, int rank, char id[PRB_COMM_ID_BYTES]) {
-  if (rank == 0) {
-    if (prb_comm_unique_id(id)) die(std::string("Error: ") + prb_last_error());
-    const std::string tmp = path + ".tmp";
-    std::FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f || std::fwrite(id, 1, PRB_COMM_ID_BYTES, f) != PRB_COMM_ID_BYTES || std::fclose(f) || std::rename(tmp.c_str(), path.c_str()))
-      die("Error: can't write the rendezvous file " + path);
-    return;
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  const time_t started = std::time(nullptr);
-  for (;;) {
-    struct stat st;
-    if (stat(path.c_str(), &st) == 0 && st.st_size == PRB_COMM_ID_BYTES && st.st_mtime + 120 >= started) { // (not a stale file of an earlier run)
-      std::FILE *f = std::fopen(path.c_str(), "rb");
-      if (f && std::fread(id, 1, PRB_COMM_ID_BYTES, f) == PRB_COMM_ID_BYTES) {
-        std::fclose(f);
-        return;
-      }
-      if (f) std::fclose(f);
+// The RCCL id of a multi-process run travels through files in the `-p` directory.  A file left behind by a run that
+// died must never be taken for this run's (ncclCommInitRank would wait for ever on a stale id), and file times say
+// nothing reliable about that, so the exchange is a handshake: every other rank writes a random nonce to
+// `<path>.hello.<rank>`; rank 0 publishes `<path>` = the id followed by the nonces it has seen, and publishes again
+// whenever a hello file changes (a stale hello of a dead run is simply overwritten by the live rank); a rank takes
+// the id only from a file that carries ITS nonce.  Rank 0 keeps publishing until its communicator exists - which is
+// when every rank has the id - and then removes the files.  A rank that fails kills the job under torchrun / mpirun;
+// started by hand, the others give up after PRB_RENDEZVOUS_TIMEOUT seconds (default 300) instead of waiting for it.
+struct Rendezvous {
+  std::string path;
+  int world = 1, rank = 0;
+  char id[PRB_COMM_ID_BYTES] = {};
+  std::thread publisher;
+  std::atomic<bool> stop{false};
+
+  static uint64_t nonce() {
+    uint64_t v = 0;
+    if (std::FILE *f = std::fopen("/dev/urandom", "rb")) {
+      if (std::fread(&v, sizeof v, 1, f) != 1) v = 0;
+      std::fclose(f);
     }
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) die("Error: no rendezvous file " + path + " from rank 0");
-    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    return v ? v : ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
   }
-}
+  static bool write_atomic(const std::string &p, const void *data, size_t n) {
+    const std::string tmp = p + ".tmp";
+    std::FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(data, 1, n, f) == n;
+    return (std::fclose(f) == 0) && ok && std::rename(tmp.c_str(), p.c_str()) == 0;
+  }
+  static bool read_exact(const std::string &p, void *data, size_t n) {
+    struct stat st;
+    if (stat(p.c_str(), &st) != 0 || (size_t)st.st_size != n) return false;
+    std::FILE *f = std::fopen(p.c_str(), "rb");
+    if (!f) return false;
+    const bool ok = std::fread(data, 1, n, f) == n;
+    std::fclose(f);
+    return ok;
+  }
+  static int timeout_s() {
+    const char *e = std::getenv("PRB_RENDEZVOUS_TIMEOUT");
+    return e ? std::max(1, std::atoi(e)) : 300;
+  }
+  std::string hello(int r) const { return path + ".hello." + std::to_string(r); }
+
+  void begin(const std::string &p, int world_, int rank_) {
+    path = p;
+    world = world_;
+    rank = rank_;
+    const size_t full = PRB_COMM_ID_BYTES + 8 * (size_t)(world - 1);
+    if (rank == 0) {
+      std::remove(path.c_str());
+      std::remove((path + ".tmp").c_str());
+      if (prb_comm_unique_id(id)) die(std::string("Error: ") + prb_last_error());
+      if (world == 1) return;
+      publisher = std::thread([this, full] {
+        std::vector<uint64_t> seen((size_t)(world - 1), 0), now((size_t)(world - 1), 0);
+        std::vector<char> buf(full);
+        while (!stop.load()) {
+          bool all = true;
+          for (int r = 1; r < world; r++) all = read_exact(hello(r), &now[(size_t)r - 1], 8) && now[(size_t)r - 1] != 0 && all;
+          if (all && now != seen) {
+            std::memcpy(buf.data(), id, PRB_COMM_ID_BYTES);
+            std::memcpy(buf.data() + PRB_COMM_ID_BYTES, now.data(), 8 * now.size());
+            if (!write_atomic(path, buf.data(), full)) die("Error: can't write the rendezvous file " + path);
+            seen = now;
+          }
+          std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+      });
+      return;
+    }
+    const uint64_t mine = nonce();
+    if (!write_atomic(hello(rank), &mine, 8)) die("Error: can't write the rendezvous file " + hello(rank));
+    std::vector<char> buf(full);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      uint64_t got = 0;
+      if (read_exact(path, buf.data(), full)) std::memcpy(&got, buf.data() + PRB_COMM_ID_BYTES + 8 * (size_t)(rank - 1), 8);
+      if (got == mine) break;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s()))
+        die("Error: no rendezvous file " + path + " from rank 0 (is it running? a rank that fails must end the whole job)");
+      std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    std::memcpy(id, buf.data(), PRB_COMM_ID_BYTES);
+  }
+  // after prb_comm_create returned on this rank (on rank 0: every rank has joined the communicator, so has the id)
+  void end() {
+    if (rank != 0) return;
+    stop.store(true);
+    if (publisher.joinable()) publisher.join();
+    std::remove(path.c_str());
+    for (int r = 1; r < world; r++) std::remove(hello(r).c_str());
+  }
+};
 
 int ris_main(int argc, char **argv) {
   Args a;
@@ -397,12 +467,21 @@ int ris_main(int argc, char **argv) {
   }
   prb_comm *comm = nullptr;
   if (rank_mode) {
-    char id[PRB_COMM_ID_BYTES];
-    const char *port = std::getenv("MASTER_PORT");
-    const std::string path = (a.tmp.empty() ? a.out : a.tmp + "/prb") + ".rccl_id." + (port ? port : "0");
-    exchange_comm_id(path, rank, id);
-    if (prb_comm_create(workers[0].ctx, world, rank, id, &comm)) die(std::string("Error: ") + prb_last_error());
-    if (rank == 0) std::remove(path.c_str()); // every rank has read it: the communicator exists
+    // one file name per launch where the launcher names the launch (torchrun: TORCHELASTIC_RUN_ID; Open MPI: its job id;
+    // or PRB_RUN_ID), else per MASTER_PORT
+    std::string token;
+    for (const char *k : {"PRB_RUN_ID", "TORCHELASTIC_RUN_ID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE", "MASTER_PORT"})
+      if (const char *e = std::getenv(k); e && *e && std::strcmp(e, "none") != 0) {
+        token = e;
+        break;
+      }
+    for (char &ch : token)
+      if (!std::isalnum((unsigned char)ch) && ch != '-' && ch != '_') ch = '_';
+    const std::string path = (a.tmp.empty() ? a.out : a.tmp + "/prb") + ".rccl_id." + (token.empty() ? "0" : token);
+    Rendezvous rdv;
+    rdv.begin(path, world, rank);
+    if (prb_comm_create(workers[0].ctx, world, rank, rdv.id, &comm)) die(std::string("Error: ") + prb_last_error());
+    rdv.end();
   }
   const bool writer_rank = rank == 0;
   prb_db_info(workers[0].db, &hash_size, &repeat_flag, &W, &delta, &npages);
@@ -446,8 +525,12 @@ int ris_main(int argc, char **argv) {
   LineSink sink; // text lines go straight to the descriptor (nothing else is written through `out` meanwhile)
   sink.fd = fileno(out);
 
+  // Queries per batch: PRB_BATCH, else large batches (full launches of the small-list kernels) but at least four per
+  // worker / rank, so that every GPU has work and the last round is short (the reference deals single queries)
   const char *benv = std::getenv("PRB_BATCH");
-  const size_t batch = std::max(1, benv ? std::atoi(benv) : 2048);
+  const size_t consumers = rank_mode ? (size_t)world : devices.size();
+  const size_t batch = benv ? (size_t)std::max(1, std::atoi(benv))
+                            : std::max<size_t>(16, std::min<size_t>(2048, (seqs.size() + 4 * consumers - 1) / (4 * consumers)));
   // longest first (stable: equal lengths keep their FASTA order), then batches in that order
   std::vector<size_t> order(seqs.size());
   std::iota(order.begin(), order.end(), (size_t)0);

@@ -15,11 +15,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def shares(nq, world):
-    """round 0: ragged shares, the LAST rank gets none; round 1: only the last rank has queries"""
+    """round 0: ragged shares for every rank (hits of the higher ranks lie behind the lower ranks' queries and pairs:
+    k_rebase_hits with non-zero bases); round 1: the LAST rank has none; round 2: only the last rank has queries"""
+    cut = np.linspace(0, nq, world + 1).astype(int)
+    cut[1] = max(1, cut[1] - 1)  # ragged
+    r0 = [list(range(cut[k], cut[k + 1])) for k in range(world)]
     cut = np.linspace(0, nq, world).astype(int)  # world - 1 shares
-    r0 = [list(range(cut[k], cut[k + 1])) for k in range(world - 1)] + [[]]
-    r1 = [[] for _ in range(world - 1)] + [list(range(0, nq, 2))]
-    return [r0, r1]
+    r1 = [list(range(cut[k], cut[k + 1])) for k in range(world - 1)] + [[]]
+    r2 = [[] for _ in range(world - 1)] + [list(range(0, nq, 2))]
+    return [r0, r1, r2]
 
 
 def main():
@@ -86,7 +90,7 @@ def main():
                     assert len(g.hits) == len(wh) and np.array_equal(g.hits, wh), (len(g.hits), len(wh))
                     assert np.array_equal(g.bp, wb)
                     checked += len(wh)
-                    del g
+                    del g  # (`got` still holds the gathered set: the last one outlives comm.close() below - allowed)
         db.close()
         comm.close()
     np.savez(result, checked=checked, rebased=rebased)

@@ -1,7 +1,9 @@
 """world_size-2 test (gloo, CPU) of the multi-process plumbing used for N > 1: disjoint query batches per
-rank, and the semantics of the final hit gather (prb_gather_hits; here its host statement
-priblast_amd.dist.gather_batch_host): hits AND base pairs of every rank on the root, `query` and
-`bp_offset` rebased, so that the root can print every result line."""
+rank, and the semantics of the final hit gather: hits AND base pairs of every rank on the root, `query` and
+`bp_offset` rebased, so that the root can print every result line.  The product's gather (prb_gather_hits,
+csrc/capi_comm.hip) needs a GPU and is EXECUTED with two and three ranks by tests/test_gpu_multirank.py; what
+runs here on the CPU is its placement rule, the library's own prb_gather_plan, for 2-8 ragged / empty ranks,
+and the host statement of the same semantics (priblast_amd.dist.gather_batch_host) checked against that rule."""
 import os
 import tempfile
 import sys
@@ -86,6 +88,45 @@ def test_two_rank_sharding_and_gather():
     assert root[1] == want
     assert root[2] == [3, 2] and root[3] == [0, 1, 2, 100, 101]
     assert root[4] == 7 and root[5] == [3, 0]
+
+
+def test_gather_plan_of_the_library():
+    """prb_gather_plan (pure host code of the product library): where the root puts each rank's hits, pair ints and
+    queries.  2-8 ranks, ragged and empty shares; the result does not depend on which rank is the root."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    from priblast_amd import capi
+    lib = capi.lib()
+    rng = np.random.default_rng(5)
+    for n in range(1, 9):
+        for trial in range(20):
+            counts = rng.integers(0, 50, (n, 3)).astype(np.int64)
+            counts[:, 1] *= 2                      # pair ints come in twos
+            counts[rng.random(n) < 0.3] = 0        # ranks without a batch in this round
+            bases = np.full((n + 1, 3), -1, np.int64)
+            assert lib.prb_gather_plan(n, counts.ctypes.data, bases.ctypes.data) == 0
+            want = np.concatenate([np.zeros((1, 3), np.int64), np.cumsum(counts, axis=0)])
+            assert np.array_equal(bases, want)
+    bad = np.array([[1, 3, 1]], np.int64)          # an odd number of pair ints
+    out = np.zeros((2, 3), np.int64)
+    assert lib.prb_gather_plan(1, bad.ctypes.data, out.ctypes.data) != 0
+    assert lib.prb_gather_plan(0, bad.ctypes.data, out.ctypes.data) != 0
+    big = np.array([[0, 0, 2 ** 31 - 1], [0, 0, 1]], np.int64)
+    out = np.zeros((3, 3), np.int64)
+    assert lib.prb_gather_plan(2, big.ctypes.data, out.ctypes.data) != 0   # query indices are 32-bit
+
+
+def test_host_statement_follows_the_plan():
+    """gather_batch_host (what the two-rank gloo test above runs) places and rebases exactly as prb_gather_plan says"""
+    sys.path.insert(0, ROOT)
+    from priblast_amd import capi
+    parts = [_make(r, capi) for r in range(2)]
+    counts = np.array([[len(h), 2 * len(b), len(q)] for h, b, _, q in parts], np.int64)
+    bases = np.zeros((3, 3), np.int64)
+    assert capi.lib().prb_gather_plan(2, counts.ctypes.data, bases.ctypes.data) == 0
+    # rank 1's records start behind rank 0's 7 hits; its queries are shifted by 3, its pair offsets by rank 0's pairs
+    assert bases[1].tolist() == [7, 2 * len(parts[0][1]), 3]
+    assert bases[2].tolist() == [12, 2 * (len(parts[0][1]) + len(parts[1][1])), 5]
 
 
 def test_longest_first_dealing():

@@ -56,6 +56,10 @@ def test_rank_mode_with_several_ranks_writes_the_single_process_file(golden_dir,
     plain = str(tmp_path / "plain.txt")
     subprocess.run([capi.BIN_PATH, "ris", "-o", plain] + common, check=True, env=_env(tmp_path, fake_rccl, PRB_BATCH=str(batch)))
     (tmp_path / "rdv").mkdir()
+    # what a run that died leaves behind in the same directory under the same MASTER_PORT: an id file of the right size and a
+    # hello file - neither may be taken for this run's (ris_main.cpp: Rendezvous)
+    (tmp_path / "rdv" / "prb.rccl_id.29731").write_bytes(b"\x07" * (128 + 8 * (world - 1)))
+    (tmp_path / "rdv" / "prb.rccl_id.29731.hello.1").write_bytes(b"\x07" * 8)
     out = str(tmp_path / "ranked.txt")
     procs = []
     for r in range(world):
@@ -83,3 +87,28 @@ def test_native_gather_with_several_ranks(golden_dir, tmp_path, fake_rccl, world
     res = np.load(str(tmp_path / f"res{root}.npz"))
     assert int(res["checked"]) > 20      # hits went through the gather ...
     assert int(res["rebased"]) > 0       # ... some of them behind other ranks' queries and pairs (k_rebase_hits)
+
+
+def test_bench_self_launches_two_ranks(tmp_path, fake_rccl):
+    """`python bench.py --gpus 2` as the driver starts it (no launcher, no WORLD_SIZE): it starts the two ranks itself
+    and rank 0 prints the one JSON line.  Rehearsed on the one GPU of the box: both ranks on device 0, gloo for
+    torch.distributed, the file transport for the hit gather (bench.py: BENCH_SHARE_GPU / BENCH_DIST_BACKEND)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = _env(tmp_path, fake_rccl, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", BENCH_WORKDIR=str(tmp_path / "work"))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--db-seqs", "200", "--length", "300", "--queries", "3", "--steps", "2",
+           "--warmup", "1", "--cpu-queries", "0"]
+    two = subprocess.run(cmd + ["--gpus", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, two.stdout
+    r2 = json.loads(lines[0])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "weak" and r2["value"] > 0 and "roofline" in r2
+    # weak scaling: the same 2 x 3 queries per rank -> rank 0 printed the lines of 12 queries; one rank alone prints 6 of them
+    env1 = dict(env)
+    one = subprocess.run(cmd + ["--gpus", "1", "--queries", "6"], env=env1, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.strip()][0])
+    # the two ranks of step k work on queries [6k, 6k + 3) and [6k + 3, 6k + 6): together the batch one rank takes with 6 per step
+    assert r2["config"]["result_lines_per_step"] == r1["config"]["result_lines_per_step"] > 0
+    assert r2["config"]["hits_per_step"] == r1["config"]["hits_per_step"]
