@@ -53,7 +53,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
-STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped_lane", "gapped_lane_hits", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait", "host_search_range", "host_cands", "host_drain_tail", "host_download")
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped_front", "gapped_front_hits", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait", "host_search_range", "host_cands", "host_drain_tail", "host_download")
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_gapped_traffic.json")
 
 
@@ -492,7 +492,7 @@ def main():
                        "parallelism": f"queries sharded over {world} GPU(s)" + (", final hits gathered on rank 0 over RCCL" if multi else "")},
             "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
-            "lane_kernel_hits_per_step": ctx.stage_ms("gapped_lane_hits")[1] // a.steps,
+            "front_kernel_hits_per_step": ctx.stage_ms("gapped_front_hits")[1] // a.steps,
             "host_wall_ms_per_step": {k: round(v / a.steps * 1e3, 1) for k, v in wall.items()},
             "roofline": {"bound": "hbm", "kernel": "k_gapped_lds<0, Tier0, Rec32, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(gap_units / max(gap_launch, 1)),

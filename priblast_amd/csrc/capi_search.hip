@@ -48,7 +48,7 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, laneScratch;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch;
   // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
   // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
   // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
@@ -104,7 +104,7 @@ struct SearchWs {
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &laneScratch})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch})
       b->release();
     front.release();
     if (copy_stream) {
@@ -1431,22 +1431,23 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     int64_t m = nung;
     uint32_t *bufs[2] = {w.listA.as<uint32_t>(), w.listB.as<uint32_t>()};
     int nb = 0;
-    // In front of the cascade, on request (PRB_GAPPED_LANE; not faster yet, see gapped_lane.hip): a lane per hit for
-    // the extensions that stay small - most of them.  What it completes is reported as tier 0 (whose capacities
-    // cover it, should such a hit be re-extended for its pairs).
-    if (cascade[0] == 0 && getenv("PRB_GAPPED_LANE") && gapped_lane_supported(sc, eo)) {
-      if ((rc = w.laneScratch.ensure(gapped_lane_scratch_bytes()))) return rc;
+    // In front of the cascade (gapped_front.hip; PRB_GAPPED_FRONT=0 leaves it out): the hits neither direction of which
+    // finds anything - four in five - are completed by a kernel that only has to prove that.  What it completes is
+    // reported as tier 0 (such a hit has no traced pairs: nothing is ever re-extended for it).
+    const char *fe = getenv("PRB_GAPPED_FRONT");
+    if (cascade[0] == 0 && !(fe && atoi(fe) == 0) && gapped_front_supported(sc, eo)) {
+      if ((rc = w.frontScratch.ensure(gapped_front_scratch_bytes()))) return rc;
       if ((rc = ctx->time_begin())) return rc;
-      PRB_HIP(launch_gapped_lane(U, G, m, cur, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
-                                 w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), w.count.as<unsigned long long>() + 1,
-                                 w.laneScratch.p, ctx->stream));
+      PRB_HIP(launch_gapped_front(U, G, m, cur, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
+                                  w.ntrace.as<int32_t>(), w.count.as<unsigned long long>() + 1, w.frontScratch.p, ctx->stream));
       int64_t rest = 0;
       if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
+      if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[front] hits %lld, go on %lld\n", (long long)m, (long long)rest);
       cur = bufs[nb];
       nb ^= 1;
-      ctx->timers["gapped_lane_hits"].launches += m - rest; // (a counter, not a time: hits completed by the lane kernel)
+      ctx->timers["gapped_front_hits"].launches += m - rest; // (a counter, not a time: hits completed by the front kernel)
       m = rest;
-      if ((rc = ctx->time_end("gapped_lane", 1))) return rc;
+      if ((rc = ctx->time_end("gapped_front", 1))) return rc;
     }
     for (size_t c = 0; c < cascade.size() && m > 0; c++) {
       const int tier = cascade[c];

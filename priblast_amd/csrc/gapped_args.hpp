@@ -1,5 +1,5 @@
 // What the gapped-extension kernels share (gapped_lds.hip: a group of lanes per hit, state in LDS or HBM
-// scratch; gapped_lane.hip: a lane per hit): the kernel arguments, the cell record of the LDS forms,
+// scratch; gapped_front.hip: the kernel in front of them): the kernel arguments, the cell record of the LDS forms,
 // the origin of a direction and the hand-over mark between kernels of the cascade.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -73,7 +73,6 @@ struct GapArgs {
   // mode 0: state dumps of hits that outgrow an LDS tier, for the next one to continue from
   // (slot[x] = -1: none): `rin` = what this kernel may continue, `rout` = where it leaves its own
   GapResume rin, rout;
-  void *lane_scratch = nullptr; // gapped_lane.hip: a LaneAcc block per wavefront of the grid
 };
 
 

@@ -215,15 +215,17 @@ constexpr int kTraceCap = 32;
 // ids of the gapped kernels a hit can be completed by (tier_out): LDS tiers 0..3, then the
 // wavefront-per-hit kernel with its state in HBM scratch
 constexpr int kLdsTiers = 4, kWaveTier = 4;
-// launch_gapped_lane (gapped_lane.hip): the first kernel of the cascade, a lane per hit, kLaneCapD anti-diagonals and
-// kLaneCapR filled cells per direction; hits that outgrow it are flagged in overflow[] (with direction 0
-// handed over when it was completed) and go on to the LDS tiers.  Completed hits are reported as `tier_id`.
-constexpr int kLaneCapD = 27, kLaneCapR = 48;
-size_t gapped_lane_scratch_bytes(); // HBM scratch of a launch (accessibility sums of the resident wavefronts)
-bool gapped_lane_supported(const SearchConst &sc, const ExtOpts &o);
-hipError_t launch_gapped_lane(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
-                              const SearchConst &sc, ExtOpts o, int tier_id, uint8_t *overflow, uint8_t *tier_out, int32_t *bp_count,
-                              uint16_t *trace, unsigned long long *next_work, void *scratch, hipStream_t s);
+// launch_gapped_front (gapped_front.hip): the kernel in front of the cascade.  It proves that a direction finds nothing
+// within its `-x` anti-diagonals (phases that are dense over directions / filled cells / (cell, candidate) pairs of 64
+// directions at a time) and completes the hits whose two directions both find nothing; the others are flagged in
+// overflow[] (with direction 0 handed over when it found nothing) and go on to the LDS tiers.  Completed hits are
+// reported as `tier_id`.  Takes -x <= kFrontMaxDrop.
+constexpr int kFrontMaxDrop = 16;
+bool gapped_front_supported(const SearchConst &sc, const ExtOpts &o);
+size_t gapped_front_scratch_bytes(); // HBM scratch of a launch (accessibility sums of the resident wavefronts; stays in L2)
+hipError_t launch_gapped_front(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
+                               const SearchConst &sc, ExtOpts o, int tier_id, uint8_t *overflow, uint8_t *tier_out, int32_t *bp_count,
+                               unsigned long long *next_work, void *scratch, hipStream_t s);
 hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                             const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
                             const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);

@@ -2,10 +2,10 @@
 # PMC counters of one kernel on the GPU box: one rocprofv3 pass per counter set (never together with a trace
 # domain other than --kernel-trace), bench.py on the small C2-shaped workload (5,000 x 1 kb database, 64 queries,
 # one step) unless BENCH_ARGS says otherwise.  Sums per kernel are printed by tools/pmc_summary.py.
-# usage (through gpurun): bash tools/pmc_kernel.sh 'k_gapped_lane' [tag] > gpurun_out/pmc_lane.txt
+# usage (through gpurun): bash tools/pmc_kernel.sh 'k_gapped_front' [tag] > gpurun_out/pmc_front.txt
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-KERNEL=${1:-k_gapped_lane}
+KERNEL=${1:-k_gapped_front}
 TAG=${2:-pmc_kernel}
 ARGS=${BENCH_ARGS:---db-seqs 5000 --length 1000 --steps 1 --warmup 0 --queries 64 --cpu-queries 0 --no-overlap}
 OUT=$R/gpurun_out/$TAG
