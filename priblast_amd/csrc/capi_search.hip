@@ -1435,6 +1435,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     // finds anything - four in five - are completed by a kernel that only has to prove that.  What it completes is
     // reported as tier 0 (such a hit has no traced pairs: nothing is ever re-extended for it).
     const char *fe = getenv("PRB_GAPPED_FRONT");
+    bool front_ran = false;
     if (cascade[0] == 0 && !(fe && atoi(fe) == 0) && gapped_front_supported(sc, eo)) {
       if ((rc = w.frontScratch.ensure(gapped_front_scratch_bytes()))) return rc;
       if ((rc = ctx->time_begin())) return rc;
@@ -1447,10 +1448,14 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       nb ^= 1;
       ctx->timers["gapped_front_hits"].launches += m - rest; // (a counter, not a time: hits completed by the front kernel)
       m = rest;
+      front_ran = true;
       if ((rc = ctx->time_end("gapped_front", 1))) return rc;
     }
+    const char *skip_env = getenv("PRB_GAPPED_SKIP_TIERS"); // experiment: bit t set = LDS tier t is left out behind the front kernel
+    const int skip_mask = (front_ran && skip_env) ? atoi(skip_env) : 0;
     for (size_t c = 0; c < cascade.size() && m > 0; c++) {
       const int tier = cascade[c];
+      if (tier < kLdsTiers - 1 && ((skip_mask >> tier) & 1)) continue;
       if (tier == kWaveTier && front_free && !front_called) { // (see below: the longest extensions run nearly alone)
         front_free();
         front_called = true;

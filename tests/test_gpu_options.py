@@ -88,7 +88,7 @@ def test_unsupported_options_fail_loudly(ctx, golden_dir):
         with pytest.raises(capi.PrbError):  # beyond the reference's 31-entry loop tables
             capi.search_page(ctx, qb, db, 0, capi.default_opts(drop_out_w_gap=31))
         with pytest.raises(capi.PrbError):
-            ctx.accessibility(["ACGU" * 10], 200, 5)  # maximal span beyond the kernel's window
+            ctx.accessibility(["ACGU" * 10], 256, 5)  # maximal span beyond the kernels' four passes of 64 cells
     finally:
         qb.close()
         db.close()
