@@ -61,15 +61,15 @@ __device__ unsigned long long g_front_prof[32];
 namespace {
 
 constexpr int kFD = kFrontMaxDrop; // anti-diagonals covered: the largest -x this kernel takes
-constexpr int kFR = 20;            // cells per direction, the start included
+constexpr int kFR = 24;            // cells per direction, the start included
 constexpr int kFWaves = 1;         // wavefronts per workgroup: one
 // Directions per wavefront.  The per-direction phases leave the lanes beyond them idle, the pooled phases use all 64; a
 // wavefront's time is the latency of its chain of phases (LDS and L2 round trips), so what counts is how many wavefronts a
 // compute unit holds: 64 directions = 22 KB of LDS = 7 wavefronts per compute unit, 27 ms per configs[2] launch; 32
 // directions = 12 KB = 12 wavefronts (then the registers are the limit).
 constexpr int kFDirs = 64;
-constexpr int kFCells = 256;      // filled cells of a wavefront's directions in one step (two anti-diagonals)
-constexpr int kFPairs = 320;      // (cell, candidate) pairs in one round of at most 64 cells
+constexpr int kFCells = 192;      // filled cells of a wavefront's directions in one step (two anti-diagonals)
+constexpr int kFPairs = 256;      // (cell, candidate) pairs in one round of at most 64 cells
 
 // the part of SearchTab every loop class but the 1x1 / 1x2 / 2x1 / 2x2 interior loops reads from, staged in LDS
 struct FrontTab {
