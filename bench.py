@@ -28,9 +28,12 @@ submitted inside the timed region is finished inside it.  Weak scaling: every ra
 writes all lines.
 
 One JSON line is printed by rank 0 (contract in the task description) with
-  roofline     : dominant kernel (k_gapped_lds<0, Tier0, Rec32, true>: tier 0, two anti-diagonals per step) - algorithmic bytes = 600 B per post-ungapped hit
-                 (DESIGN.md "Measurement") / device time from HIP events on the
-                 library's stream, against the 8 TB/s HBM peak;
+  roofline     : the gapped kernel that takes longest - k_gapped_front (every post-ungapped hit) or tier 0 of the LDS
+                 cascade (the hits the front kernel hands on): algorithmic bytes = 600 B per post-ungapped hit
+                 (DESIGN.md "Measurement") / device time from HIP events on the library's stream,
+                 against the 8 TB/s HBM peak; traffic, VALU instructions per hit, active lanes and VALU issue share
+                 from the committed PMC passes (profiles/r03_pmc_gapped_*.json); stage_roofline has both kernels, the
+                 gapped stage as a whole, the pairs -> hits stage and Raccess;
   cpu_baseline : the unmodified reference (oracle/_ref/pRIblast.shipped, OpenMP) on the same queries
                  against the first 1/`--cpu-db-fraction` of the same database built as a database of its own
                  (a full-database query costs the reference ~760 core-seconds), with the measured rate,
@@ -54,7 +57,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
 STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped_front", "gapped_front_hits", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait", "host_search_range", "host_cands", "host_drain_tail", "host_download")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_gapped_traffic.json")
+SEED_BYTES_PER_HIT = 136.0     # SA entry + start_pos probe + code window + ~25 accessibility floats per seed hit
+RACCESS_BYTES_PER_NT = 8100.0  # 7 band tables x 72 x 8 B written once + read ~once
+RACCESS_LSE_PER_NT = 12400.0   # logsumexp per nucleotide (W = 70)
+# PMC passes of the two gapped kernels that matter, on this very workload (tools/pmc_kernel.sh; one rocprofv3 --pmc pass per
+# counter set): HBM traffic per unit (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), VALU instructions per unit, active lanes
+PMC_FILES = {"k_gapped_front": os.path.join(ROOT, "profiles", "r03_pmc_gapped_front.json"),
+             "k_gapped_lds<0, Tier0, Rec32, true>": os.path.join(ROOT, "profiles", "r03_pmc_gapped_tier0.json")}
 
 
 def parse():
@@ -75,17 +84,29 @@ def parse():
     return ap.parse_args()
 
 
-def measured_traffic(units_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per hit; tools/pmc_passes.sh)."""
-    for path in (TRAFFIC_FILE, os.path.join(ROOT, "profiles", "r01_gapped_traffic.json")):
-        try:
-            with open(path) as f:
-                per_unit = json.load(f)["bytes_per_unit"]["traffic_corrected_total"]
-            return per_unit * units_per_launch
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+def pmc_of(kernel):
+    """what the committed PMC passes say about a kernel, per unit (post-ungapped hit): {} if there is no file"""
+    try:
+        with open(PMC_FILES[kernel]) as f:
+            d = json.load(f)
+        return {"traffic_bytes_per_unit": d["bytes_per_unit"]["traffic_corrected_total"], **d["per_unit"]}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def kernel_roofline(kernel, units, ms, launches, bytes_per_unit):
+    """HBM roofline entry of one kernel: algorithmic bytes x units / device time (HIP events on the library's stream)"""
+    achieved = (units * bytes_per_unit / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    pmc = pmc_of(kernel) if kernel in PMC_FILES else {}
+    per_launch = units / max(launches, 1)
+    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": pmc["traffic_bytes_per_unit"] * per_launch if "traffic_bytes_per_unit" in pmc else None,
+         "launches": launches, "avg_launch_ms": ms / max(launches, 1), "units_per_launch": per_launch, "bytes_per_unit": bytes_per_unit,
+         "ns_per_unit": ms * 1e6 / max(units, 1)}
+    # these kernels are bound by instruction issue, not by HBM: the numbers that say so, from the same PMC passes
+    for k in ("valu_insts_per_unit", "active_lanes_per_inst", "valu_issue_frac"):
+        r[k] = pmc.get(k)
+    return r
 
 
 def host_cores():
@@ -467,9 +488,17 @@ def main():
 
     if rank == 0:
         nq = a.queries * a.steps * world
+        # the two kernels that share the gapped stage: the front kernel sees every post-ungapped hit, tier 0 of the LDS
+        # cascade what the front kernel hands on (every hit, without it); the roofline entry is the one that takes longer
+        front_ms, front_launch = stage["gapped_front"]
+        front_done = ctx.stage_ms("gapped_front_hits")[1]
         gap_ms, gap_launch = stage["gapped"]
-        gap_units = counts[1]  # post-ungapped hits this rank extended
-        achieved = (gap_units * GAPPED_BYTES_PER_HIT / 1e9) / (gap_ms / 1e3) if gap_ms > 0 else 0.0
+        rl_front = kernel_roofline("k_gapped_front", counts[1], front_ms, front_launch, GAPPED_BYTES_PER_HIT)
+        rl_tier0 = kernel_roofline("k_gapped_lds<0, Tier0, Rec32, true>", counts[1] - front_done, gap_ms, gap_launch, GAPPED_BYTES_PER_HIT)
+        gapped_all_ms = sum(stage[s][0] for s in ("gapped_front", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow"))
+        ung_ms, ung_launch = stage["ungapped"]
+        ra_ms, ra_launch = stage["raccess"]
+        ra_nt = a.queries * a.steps * a.length
         res = {
             "metric": "query RNAs/sec in `ris` step",
             "value": nq / dt,
@@ -494,11 +523,19 @@ def main():
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
             "front_kernel_hits_per_step": ctx.stage_ms("gapped_front_hits")[1] // a.steps,
             "host_wall_ms_per_step": {k: round(v / a.steps * 1e3, 1) for k, v in wall.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_gapped_lds<0, Tier0, Rec32, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(gap_units / max(gap_launch, 1)),
-                         "launches": gap_launch, "avg_launch_ms": gap_ms / max(gap_launch, 1),
-                         "units_per_launch": gap_units / max(gap_launch, 1), "bytes_per_unit": GAPPED_BYTES_PER_HIT,
-                         "ns_per_unit": gap_ms * 1e6 / max(gap_units, 1)},
+            "roofline": rl_front if front_ms >= gap_ms else rl_tier0,
+            "stage_roofline": {
+                "k_gapped_front": rl_front, "k_gapped_lds_tier0": rl_tier0,
+                "gapped_stage_all_kernels": {"bound": "hbm", "units": counts[1], "bytes_per_unit": GAPPED_BYTES_PER_HIT,
+                                             "achieved": counts[1] * GAPPED_BYTES_PER_HIT / 1e9 / (gapped_all_ms / 1e3) if gapped_all_ms > 0 else 0.0,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": gapped_all_ms / a.steps,
+                                             "ns_per_unit": gapped_all_ms * 1e6 / max(counts[1], 1)},
+                "pairs_to_hits (k_pair_key + sort + k_seed_extend + k_collect_slices)": kernel_roofline(
+                    "k_seed_extend", counts[0], ung_ms, ung_launch, SEED_BYTES_PER_HIT),
+                "raccess (k_inside + k_outside + k_biloop + k_access, second stream)": {
+                    "bound": "fp64 latency (one wavefront per sequence)", "units_nt": ra_nt, "bytes_per_unit": RACCESS_BYTES_PER_NT,
+                    "achieved": ra_nt * RACCESS_BYTES_PER_NT / 1e9 / (ra_ms / 1e3) if ra_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "logsumexp_per_s": ra_nt * RACCESS_LSE_PER_NT / (ra_ms / 1e3) if ra_ms > 0 else 0.0, "ms_per_step": ra_ms / a.steps}},
         }
         # (N > 1: the other ranks wait at the closing barrier meanwhile; the sample is bounded to ~20 s of wall time)
         res["cpu_baseline"] = cpu_baseline(a, ctx, a.workdir, qnames, qseqs, log)

@@ -161,6 +161,36 @@ def test_2kb_vs_2kb_c3_shape_against_reference_binary(ctx, tmp_path):
     assert a == b
 
 
+def test_config1_full_database_against_reference_binary(ctx, tmp_path):
+    """BASELINE configs[1] at its FULL database size: 16 x 1 kb queries (the first 16 of the 5,000) vs the 5,000 x 1 kb
+    database (5 M characters), the GPU command line against the unmodified reference's strict build run on the box's
+    CPUs (~19 core-seconds per query): the same result lines - energies as printed, coordinates, Id aside."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_synthetic
+    from priblast_amd import capi
+    ref = os.path.join(ROOT, "oracle", "_ref", "pRIblast.strict")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    dbfa, qfa = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    gen_synthetic.write_fasta(dbfa, gen_synthetic.gen_fixed(5000, 1000, 1, "db"))
+    gen_synthetic.write_fasta(qfa, gen_synthetic.gen_fixed(16, 1000, 2, "q"))
+    # (the database by the GPU build - byte-identical to the reference's, test_db_build_matches_reference_files -: the
+    # reference's own `db` would take 2,000 core-seconds)
+    subprocess.run([capi.BIN_PATH, "db", "-i", dbfa, "-o", str(tmp_path / "db")], check=True)
+    env = dict(os.environ, OMP_NUM_THREADS="16")
+    subprocess.run([ref, "ris", "-i", qfa, "-o", str(tmp_path / "ref.out"), "-d", str(tmp_path / "db"), "-a", "dynamic", "-p", str(tmp_path)],
+                   check=True, env=env, cwd=str(tmp_path))
+    subprocess.run([capi.BIN_PATH, "ris", "-i", qfa, "-o", str(tmp_path / "gpu.out"), "-d", str(tmp_path / "db")], check=True)
+
+    def body(p):
+        with open(p) as f:
+            return sorted(l.split(",", 1)[1] for l in f.read().splitlines()[3:])
+    a, b = body(str(tmp_path / "gpu.out")), body(str(tmp_path / "ref.out"))
+    assert len(b) > 200000
+    assert a == b
+
+
 @pytest.mark.parametrize("repeat_flag", [1, 2])
 def test_repeat_flags_against_reference_binary(tmp_path, repeat_flag):
     """Soft-masked (lower-case) stretches with `db -r 1` / `-r 2` (encoder.cpp:38-89): the database
