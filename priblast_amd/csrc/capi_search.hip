@@ -48,7 +48,7 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
   // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
   // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
   // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
@@ -104,7 +104,7 @@ struct SearchWs {
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
       b->release();
     front.release();
     if (copy_stream) {
@@ -953,6 +953,26 @@ static int reserve_recs(prb_ctx *ctx, DevBuf &recbuf, int64_t have, int64_t more
   return recbuf.ensure(need);
 }
 
+// `need` bytes in a buffer whose first `have` bytes are kept
+static int grow_keep(prb_ctx *ctx, DevBuf &buf, size_t have, size_t need) {
+  int rc;
+  if (have > 0 && need > buf.cap) {
+    DevBuf bigger;
+    if ((rc = bigger.ensure(need + need / 2))) return rc;
+    PRB_HIP(hipMemcpyAsync(bigger.p, buf.p, have, hipMemcpyDeviceToDevice, ctx->stream));
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    buf.release();
+    buf = bigger;
+    return PRB_OK;
+  }
+  return buf.ensure(need);
+}
+// the hits from `first` on, as a list of their own
+static HitSoA offset_hits(const HitSoA &h, int64_t first) {
+  return HitSoA{h.q_sp + first, h.db_sp + first, h.q_len + first, h.db_len + first, h.db_id + first, h.db_id_start + first,
+                h.query + first, h.e_acc + first, h.e_hyb + first, h.e_tot + first};
+}
+
 static int compact_below(prb_ctx *ctx, SearchWs &w, const HitSoA &in, int64_t n, double thr, DevBuf &idxbuf, DevBuf &recbuf,
                          int64_t *m, int64_t have = 0) {
   int rc;
@@ -1288,7 +1308,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if (nung == 0) return PRB_OK;
   // compact survivors into A (A's seed content is no longer needed; the last chunk's pool may be smaller than this list)
   if ((rc = w.hitsA.ensure(hits_bytes(nung)))) return rc;
-  HitSoA U = carve_hits(w.hitsA, nung);
+  HitSoA U = carve_hits(w.hitsA, nung); // (the gapped stage below may narrow this view to a chunk of the list)
   PRB_HIP(launch_gather_hits(B, w.surv.as<uint32_t>(), U, nung, ctx->stream));
   if ((rc = w.first.ensure((size_t)nung))) return rc;
   PRB_HIP(launch_mark_first(U.query, nung, w.first.as<uint8_t>(), ctx->stream));
@@ -1314,13 +1334,27 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   }
 
   // ---- gapped extension ----
-  if ((rc = w.hitsC.ensure(hits_bytes(nung)))) return rc;
-  HitSoA G = carve_hits(w.hitsC, nung);
-  if ((rc = w.overflow.ensure((size_t)nung)) || (rc = w.subset.ensure((size_t)nung * 4)) ||
-      (rc = w.ntrace.ensure((size_t)nung * 4)) || (rc = w.tierOf.ensure((size_t)nung)) ||
-      (rc = w.listA.ensure((size_t)nung * 4)) || (rc = w.listB.ensure((size_t)nung * 4)) || (rc = w.count.ensure(16)) ||
-      (rc = w.trace.ensure((size_t)nung * 2 * kTraceCap * sizeof(uint16_t))))
+  // The state of this stage is ~350 B per hit (the extended hit, work lists, trace slots, hand-over slots): a list
+  // longer than PRB_GAPPED_CHUNK_HITS (a 45 kb query against a 100 M character page leaves 5e8 hits behind -f) goes through
+  // it in chunks of that many - the list is sorted and filtered already, the extension of a hit depends on nothing but the
+  // hit -, and only what is not above the -g threshold is kept of a chunk: the extended hit, the hit it came from, its
+  // trace slot.  The final sort + filter then run over the union, as the reference's do over the whole list
+  // (rna_interaction_search.cpp:302-320).
+  int64_t gchunk = 120000000;
+  if (const char *e = getenv("PRB_GAPPED_CHUNK_HITS")) gchunk = std::max<int64_t>(1, (int64_t)atof(e));
+  const bool chunked = nung > gchunk;
+  const int64_t nmax = chunked ? gchunk : nung;
+  if ((rc = w.hitsC.ensure(hits_bytes(nmax)))) return rc;
+  if ((rc = w.overflow.ensure((size_t)nmax)) || (rc = w.subset.ensure((size_t)nmax * 4)) ||
+      (rc = w.ntrace.ensure((size_t)nmax * 4)) || (rc = w.tierOf.ensure((size_t)nmax)) ||
+      (rc = w.listA.ensure((size_t)nmax * 4)) || (rc = w.listB.ensure((size_t)nmax * 4)) || (rc = w.count.ensure(16)) ||
+      (rc = w.trace.ensure((size_t)nmax * 2 * kTraceCap * sizeof(uint16_t))))
     return rc;
+  // the chunk the cascade below works on (the whole list, unless it is chunked): hits Uc -> Gc, per-hit arrays indexed from 0
+  const HitSoA Uall = U;
+  HitSoA G = carve_hits(w.hitsC, nmax);
+  const uint8_t *firstc = w.first.as<uint8_t>();
+  int64_t nch = nmax;
   // The cascade of kernels a hit goes through until one has the capacity for it: LDS tiers 0 and 1
   // (8 lanes per hit), tier 2 (16 lanes), tier 3 (a wavefront per hit), then the wave-per-hit kernel
   // with HBM scratch of any size.
@@ -1381,7 +1415,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       GapScratch gs;
       if ((rc = scratch_for(m, cap_diag, cap_rec, gs))) return rc;
       PRB_HIP(launch_gapped_wave(U, G, m, cur, qb->view, pd, sc, eo, gs, mode, mode == 0 ? w.overflow.as<uint8_t>() : nullptr,
-                                 mode == 0 ? w.tierOf.as<uint8_t>() : nullptr, w.first.as<uint8_t>(),
+                                 mode == 0 ? w.tierOf.as<uint8_t>() : nullptr, firstc,
                                  mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream));
       if (mode != 0) break;
       int64_t again = 0;
@@ -1401,10 +1435,15 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     }
     return PRB_OK;
   };
+  static const char *const kTierTimer[5] = {"gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow"};
+  bool front_called = false;
+  const GapResume no_resume{nullptr, nullptr, nullptr, 0};
+  // the cascade for the chunk (U, G, nch, firstc)
+  auto extend_chunk = [&]() -> int {
+  const int64_t nung = nch; // (everything below is per chunk)
   PRB_HIP(hipMemsetAsync(w.tierOf.p, 0, (size_t)nung, ctx->stream)); // no hit carries a resume mark yet
   // state dumps for the hits that outgrow tier 0 (~15 %: room for one hit in four, at most 4 M), tier 1
   // (~4 %: one in eight, at most 2 M) and tier 2 (~0.7 %: one in 32, at most 1 M); rs[t] = dumps of tier t
-  const GapResume no_resume{nullptr, nullptr, nullptr, 0};
   GapResume rs[kLdsTiers - 1] = {no_resume, no_resume, no_resume};
   static_assert(kLdsTiers == 4, "one pool of state dumps per LDS tier but the last");
   if (!getenv("PRB_GAPPED_NO_RESUME")) {
@@ -1424,8 +1463,6 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     PRB_HIP(hipMemsetAsync(w.resumeCount.p, 0, 16, ctx->stream));
     PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 4 * 3, ctx->stream));
   }
-  static const char *const kTierTimer[5] = {"gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow"};
-  bool front_called = false;
   {
     const uint32_t *cur = nullptr; // all of U
     int64_t m = nung;
@@ -1468,7 +1505,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         m = 0;
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
-                                  w.first.as<uint8_t>(), w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
+                                  firstc, w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
                                   w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,
                                   tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream));
         int64_t rest = 0;
@@ -1481,6 +1518,60 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = ctx->time_end(kTierTimer[tier], 1))) return rc;
     }
   }
+  return PRB_OK;
+  }; // extend_chunk
+
+  int64_t m2 = 0;
+  if (!chunked) {
+    if ((rc = extend_chunk())) return rc;
+  } else {
+    // chunk by chunk; of each chunk, what is not above the -g threshold is appended to the kept lists: the extended hits as
+    // records in hitsB (what the final sort takes), the hits they came from, their first-of-query flags, tiers, chain lengths
+    // and trace slots - everything the traceback of the final hits reads, indexed by position in the kept lists from now on
+    for (int64_t c0 = 0; c0 < nung; c0 += gchunk) {
+      nch = std::min<int64_t>(gchunk, nung - c0);
+      U = offset_hits(Uall, c0);
+      G = carve_hits(w.hitsC, nch);
+      firstc = w.first.as<uint8_t>() + c0;
+      if ((rc = extend_chunk())) return rc;
+      int64_t mc = 0;
+      if ((rc = ctx->time_begin())) return rc;
+      if ((rc = compact_below(ctx, w, G, nch, opts.final_threshold, w.cidx, w.hitsB, &mc, m2))) return rc;
+      if (mc > 0) {
+        if ((rc = grow_keep(ctx, w.keptU, (size_t)m2 * sizeof(HitRec), (size_t)(m2 + mc) * sizeof(HitRec))) ||
+            (rc = grow_keep(ctx, w.keptFirst, (size_t)m2, (size_t)(m2 + mc))) || (rc = grow_keep(ctx, w.keptTier, (size_t)m2, (size_t)(m2 + mc))) ||
+            (rc = grow_keep(ctx, w.keptNtrace, (size_t)m2 * 4, (size_t)(m2 + mc) * 4)) ||
+            (rc = grow_keep(ctx, w.keptTrace, (size_t)m2 * 2 * kTraceCap * 2, (size_t)(m2 + mc) * 2 * kTraceCap * 2)))
+          return rc;
+        const uint32_t *idx = w.cidx.as<uint32_t>();
+        PRB_HIP(launch_gather_hits_to_recs(U, idx, w.keptU.as<HitRec>() + m2, mc, ctx->stream));
+        PRB_HIP(launch_gather_u8(firstc, idx, w.keptFirst.as<uint8_t>() + m2, mc, ctx->stream));
+        PRB_HIP(launch_gather_u8(w.tierOf.as<uint8_t>(), idx, w.keptTier.as<uint8_t>() + m2, mc, ctx->stream));
+        PRB_HIP(launch_gather_u32(w.ntrace.as<uint32_t>(), idx, w.keptNtrace.as<uint32_t>() + m2, mc, ctx->stream));
+        PRB_HIP(launch_gather_rows(w.trace.p, idx, static_cast<uint8_t *>(w.keptTrace.p) + (size_t)m2 * 2 * kTraceCap * 2, mc,
+                                   2 * kTraceCap * 2, ctx->stream));
+      }
+      if ((rc = ctx->time_end("filter", 2))) return rc;
+      if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[gapped chunk] hits %lld at %lld of %lld, kept %lld\n", (long long)nch, (long long)c0, (long long)nung, (long long)mc);
+      m2 += mc;
+      if (m2 > (int64_t)UINT32_MAX - 16) {
+        set_error("more than 4e9 hits under the -g threshold in one sub-batch: build the database in smaller pages (db -c)");
+        return PRB_ERR_NOMEM;
+      }
+    }
+    // from here on "the hits before the gapped stage" are the kept ones, in the order they were kept
+    if (m2 > 0) {
+      if ((rc = w.hitsA.ensure(hits_bytes(m2))) || (rc = w.cidx.ensure((size_t)m2 * 4))) return rc;
+      U = carve_hits(w.hitsA, m2);
+      PRB_HIP(launch_iota_u32(w.cidx.as<uint32_t>(), m2, ctx->stream));
+      PRB_HIP(launch_gather_recs_to_hits(w.keptU.as<HitRec>(), w.cidx.as<uint32_t>(), U, m2, ctx->stream));
+    }
+  }
+  const uint8_t *first_all = chunked ? w.keptFirst.as<uint8_t>() : w.first.as<uint8_t>();
+  const uint8_t *tier_all = chunked ? w.keptTier.as<uint8_t>() : w.tierOf.as<uint8_t>();
+  const int32_t *ntrace_all = chunked ? w.keptNtrace.as<int32_t>() : w.ntrace.as<int32_t>();
+  const uint16_t *trace_all = chunked ? w.keptTrace.as<uint16_t>() : w.trace.as<uint16_t>();
+  firstc = first_all; // (the re-extension of final hits for their pairs indexes the kept lists)
 
   // The front of the NEXT sub-batch's seed path (bandwidth-bound, ~7 ms per configs[2] query) goes out here at the latest:
   // beside what is left of this sub-batch - the ~150 longest extensions on a wavefront each (2 ms, and 2 ms again for
@@ -1492,11 +1583,13 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     front_called = true;
   }
   // ---- final sort + filter (hits above the -g threshold dropped first) ----
-  int64_t m2 = 0;
-  if ((rc = ctx->time_begin())) return rc;
-  if ((rc = compact_below(ctx, w, G, nung, opts.final_threshold, w.cidx, w.hitsB, &m2))) return rc;
-  if ((rc = ctx->time_end("filter", 2))) return rc;
+  if (!chunked) {
+    if ((rc = ctx->time_begin())) return rc;
+    if ((rc = compact_below(ctx, w, G, nung, opts.final_threshold, w.cidx, w.hitsB, &m2))) return rc;
+    if ((rc = ctx->time_end("filter", 2))) return rc;
+  }
   if (m2 == 0) return PRB_OK;
+  if ((rc = w.hitsC.ensure(hits_bytes(m2)))) return rc; // (more than a chunk's worth, possibly, when the stage ran in chunks)
   HitSoA S = carve_hits(w.hitsC, m2); // G is dead after the compaction
   if ((rc = ctx->time_begin())) return rc;
   if ((rc = sort_hits(ctx, w, w.hitsB.as<HitRec>(), S, m2, qb->nq, sb, &perm))) return rc;
@@ -1512,7 +1605,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if ((rc = w.hitsB.ensure(hits_bytes(nfin)))) return rc; // (the records of the compacted list are dead after the sort)
   HitSoA F = carve_hits(w.hitsB, nfin);
   PRB_HIP(launch_gather_hits(S, w.surv.as<uint32_t>(), F, nfin, ctx->stream));
-  if ((rc = w.subset2.ensure((size_t)nfin * 4))) return rc;
+  if ((rc = w.subset2.ensure((size_t)nfin * 4)) || (rc = w.subset.ensure((size_t)nfin * 4))) return rc;
   PRB_HIP(launch_gather_u32(perm, w.surv.as<uint32_t>(), w.subset2.as<uint32_t>(), nfin, ctx->stream));
   PRB_HIP(launch_gather_u32(w.cidx.as<uint32_t>(), w.subset2.as<uint32_t>(), w.subset.as<uint32_t>(), nfin, ctx->stream));
 
@@ -1539,12 +1632,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     uint32_t *ntr = reinterpret_cast<uint32_t *>(cnt + NF);
     uint8_t *tier_fin = reinterpret_cast<uint8_t *>(ntr + NF);
     PRB_HIP(hipMemcpyAsync(pre, w.subset.p, NF * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PRB_HIP(launch_bp_count(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.ntrace.as<int32_t>(),
-                            w.bpCount.as<int32_t>(), ctx->stream));
+    PRB_HIP(launch_bp_count(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, ntrace_all, w.bpCount.as<int32_t>(), ctx->stream));
     PRB_HIP(hipMemcpyAsync(cnt, w.bpCount.p, NF * 4, hipMemcpyDeviceToHost, ctx->stream));
     // which kernel of the cascade completed each final hit, and its chain lengths
-    PRB_HIP(launch_gather_u8(w.tierOf.as<uint8_t>(), w.subset.as<uint32_t>(), w.tierFin.as<uint8_t>(), nfin, ctx->stream));
-    PRB_HIP(launch_gather_u32(w.ntrace.as<uint32_t>(), w.subset.as<uint32_t>(), w.ntraceFin.as<uint32_t>(), nfin, ctx->stream));
+    PRB_HIP(launch_gather_u8(tier_all, w.subset.as<uint32_t>(), w.tierFin.as<uint8_t>(), nfin, ctx->stream));
+    PRB_HIP(launch_gather_u32(reinterpret_cast<const uint32_t *>(ntrace_all), w.subset.as<uint32_t>(), w.ntraceFin.as<uint32_t>(), nfin,
+                              ctx->stream));
     PRB_HIP(hipMemcpyAsync(tier_fin, w.tierFin.p, NF, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipMemcpyAsync(ntr, w.ntraceFin.p, NF * 4, hipMemcpyDeviceToHost, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
@@ -1553,9 +1646,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
     PRB_HIP(hipMemcpyAsync(w.bpOff.p, off, (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, w.first.as<uint8_t>(), w.ntrace.as<int32_t>(),
-                             w.tierOf.as<uint8_t>(), w.trace.as<uint16_t>(), w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(),
-                             ctx->stream));
+    PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, first_all, ntrace_all, tier_all, trace_all,
+                             w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
     std::vector<uint32_t> tlist[kWaveTier + 1];
     std::vector<int64_t> toff[kWaveTier + 1];
     const bool no_slots = getenv("PRB_TRACE_NO_SLOTS") != nullptr; // testing: re-extend every final hit as well
@@ -1584,7 +1676,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         if ((rc = run_wave(2, w.subset2.as<uint32_t>(), m, nullptr, w.bpOff2.as<int64_t>()))) return rc;
       } else {
         PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,
-                                  w.first.as<uint8_t>(), nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
+                                  first_all, nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
                                   w.count.as<unsigned long long>() + 1, GapResume{nullptr, nullptr, nullptr, 0},
                                   GapResume{nullptr, nullptr, nullptr, 0}, ctx->stream));
       }
@@ -1882,10 +1974,11 @@ int prb_search_page(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int32_t page, cons
     {
       HostTimer ht(ctx, "host_search_range");
       rc = search_range(ctx, qb, db, page, *opts, last_stage, cd, ncand, nrows, nqent, hs, front_free);
-      if (rc == PRB_ERR_NOMEM) // (the seed pools are bounded by the chunk budget; what grows with a query is the list behind -f)
+      if (rc == PRB_ERR_NOMEM) // (the seed pools and the gapped stage's state are bounded by their chunk budgets; what grows with a
+                               //  query is the list behind -f itself, ~200 B per hit with its sort keys)
         set_error(std::string(prb_last_error()) + " - the hits of queries " + std::to_string(q0) + ".." + std::to_string(q1 - 1) +
-                  " that pass -f against this page, with the gapped extension's state, do not fit the device: build the database in "
-                  "smaller pages (db -c), which bounds them per page");
+                  " that pass -f against this page do not fit the device (lower PRB_GAPPED_CHUNK_HITS / PRB_SEARCH_CHUNK_PAIRS if it is "
+                  "their working state; else build the database in smaller pages, db -c, which bounds the list per page)");
     }
     // the pinned candidates are reused by the next sub-batch: their upload must be over
     if (rc == PRB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PRB_ERR_HIP;

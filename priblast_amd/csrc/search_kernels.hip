@@ -1108,6 +1108,34 @@ hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
   hipLaunchKernelGGL(k_gather<uint32_t>, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);
   return hipGetLastError();
 }
+namespace {
+__global__ __launch_bounds__(256) void k_iota_u32(uint32_t *dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (uint32_t)i;
+}
+// dst row r = src row idx[r]; rows of `words` 16-byte words, one thread per word
+__global__ __launch_bounds__(256) void k_gather_rows(const uint4 *__restrict__ src, const uint32_t *__restrict__ idx, uint4 *dst, int64_t n,
+                                                     int words) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = t / words;
+  if (r >= n) return;
+  const int wi = (int)(t - r * words);
+  dst[r * words + wi] = src[(int64_t)idx[r] * words + wi];
+}
+} // namespace
+hipError_t launch_iota_u32(uint32_t *dst, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_gather_rows(const void *src, const uint32_t *idx, void *dst, int64_t n, int row_bytes, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (row_bytes % 16 != 0) return hipErrorInvalidValue;
+  const int words = row_bytes / 16;
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n * words + 255) / 256)), dim3(256), 0, s, static_cast<const uint4 *>(src), idx,
+                     static_cast<uint4 *>(dst), n, words);
+  return hipGetLastError();
+}
 hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_gather<uint8_t>, grid_for(n), dim3(kBlock), 0, s, src, idx, dst, n);

@@ -131,6 +131,9 @@ hipError_t launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
 hipError_t launch_pack_hits(const HitSoA &src, int64_t n, const int32_t *bp_count, const int64_t *bp_off, int64_t bp_base,
                             void *out, hipStream_t s);
 hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s);
+hipError_t launch_iota_u32(uint32_t *dst, int64_t n, hipStream_t s); // dst[i] = i
+// dst row r = src row idx[r], rows of row_bytes (a multiple of 16) bytes
+hipError_t launch_gather_rows(const void *src, const uint32_t *idx, void *dst, int64_t n, int row_bytes, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
 // The hits between a threshold compaction and the sort behind it, one 64-byte record each: the sort
 // ends in a gather in random order, which then costs one cache line per hit instead of one per field.

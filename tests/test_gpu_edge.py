@@ -219,6 +219,37 @@ def test_query_longer_than_the_lds_staging(ctx, oracle, golden_dir):
         odb.close()
 
 
+def test_gapped_stage_in_chunks(ctx, tmp_path, monkeypatch):
+    """A query whose list behind -f is longer than the gapped stage holds at once (PRB_GAPPED_CHUNK_HITS; by default 1.2e8
+    hits - a 45 kb query against a 100 M character page leaves 5e8) is extended chunk by chunk, the survivors of -g kept
+    with their trace slots, and the final sort + filter run over the union: the same final hits and base pairs as in one
+    piece, for two chunk sizes, -s 0 and -s 1, on a 6 kb query against a 400 x 1 kb page (~3e5 hits behind -f)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_synthetic
+    from priblast_amd import capi
+    recs = gen_synthetic.gen_fixed(400, 1000, 1, "db")
+    capi.db_build(ctx, str(tmp_path / "db"), [r[0] for r in recs], [r[1] for r in recs], 0, 8, 70, 5)
+    db = capi.Db(ctx, str(tmp_path / "db"))
+    qs = [gen_synthetic.gen_fixed(1, 6000, 7, "long")[0][1], gen_synthetic.gen_fixed(1, 300, 8, "short")[0][1]]
+    qb = capi.QBatch(ctx, qs, db.repeat_flag)
+    qb.accessibility(db.W, db.delta)
+    try:
+        for style in (0, 1):
+            monkeypatch.delenv("PRB_GAPPED_CHUNK_HITS", raising=False)
+            h0, bp0, c0 = capi.search_page(ctx, qb, db, 0, capi.default_opts(output_style=style))
+            assert c0[1] > 100000 and c0[2] > 1000
+            for chunk in ("50000", "17001"):
+                monkeypatch.setenv("PRB_GAPPED_CHUNK_HITS", chunk)
+                h1, bp1, c1 = capi.search_page(ctx, qb, db, 0, capi.default_opts(output_style=style))
+                assert c1 == c0
+                assert np.array_equal(h0, h1) and np.array_equal(bp0, bp1), (style, chunk)
+    finally:
+        monkeypatch.delenv("PRB_GAPPED_CHUNK_HITS", raising=False)
+        qb.close()
+        db.close()
+
+
 def test_candidate_with_more_query_entries_than_a_pair_value_holds(ctx, oracle, golden_dir, monkeypatch):
     """A 5,000 nt poly-G query: its seed candidates have ~5,000 query suffix-array entries each, more than the 4,096 the
     one-pass form's pair value has bits for, so those chunks take the list form (search_range's `fuse = false`); a
