@@ -297,6 +297,13 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
     b.codes = ctx->ra_codes.as<unsigned char>();
     b.acc = d_acc;
     b.cond = d_cond;
+    {
+      // the LOGSUM branch of the bulge / interior sums by windows of 64 positions (which sequences take it is only known on
+      // the device, after the inside pass: the grid covers every sequence, the others' workgroups leave at once)
+      const char *e = std::getenv("PRB_RACCESS_LOGSUM_WINDOWS"); // 0: the ordered pass on the sequence's own wavefront (tests)
+      const int64_t lmax = len(order[pos]);                         // (longest first)
+      b.logsum_windows = (e && std::atoi(e) == 0) ? 0 : (int32_t)((lmax + 63) / 64);
+    }
     if ((rc = ctx->time_begin())) return rc;
     PRB_HIP(ra_launch(b, ctx->ra_const, band, vec, ctx->stream));
     if ((rc = ctx->time_end("raccess", 1))) return rc; // synchronises: host staging vectors may be reused

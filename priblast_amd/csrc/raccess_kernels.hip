@@ -1066,6 +1066,95 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
   return __ballot(undecided) == 0;
 }
 
+// The LOGSUM branch (|log Z| > 690, raccess.cpp:683-771) for a WINDOW of 64 positions: one logsumexp per (tuple,
+// position) in the reference's (i, j, p, q) order makes the ordered pass above a chain of ~5,600 tuples per nucleotide
+// on its one wavefront (2.35 ms per nucleotide: 47 s for a lone 20 kb sequence).  The sums of different positions do
+// not depend on each other, only the order WITHIN a position matters: a wavefront owns positions k0 .. k0 + 63 (one per
+// lane), walks the tuples of every i that can reach them (k - W + delta <= i <= k - 1) in the same order - the lanes
+// evaluating the tuples of one (i, j, u1) side by side, as above -, and a lane folds a tuple in only if its position lies
+// in one of the tuple's two ranges.  Every window costs what ~(W + 64) values of i cost, all windows of all sequences
+// run at once: the time of a sequence no longer grows with its length.
+__global__ __launch_bounds__(kBlock) void k_biloop_logsum(RaBatch b, RaConst c) {
+  __shared__ RaLds lds;
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.y;
+  const SeqView v = make_view(b, idx);
+  const int L = v.L, W = v.W, S = v.S, delta = b.delta;
+  const double pf = v.v(V_AO)[L];
+  // (both tests are the same for every thread of the workgroup: nobody is left waiting at the barrier of the table load)
+  if (pf >= -690 && pf <= 690) return; // the linear branch: k_biloop
+  if (1 + kWave * (int)(blockIdx.x * kWavesPerBlock) > L) return;
+  ra_load_lds(lds, c);
+  const int k0 = 1 + kWave * (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (k0 > L) return;
+  const int k = k0 + lane; // this lane's position
+  const unsigned char *s = v.s;
+  const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
+  double accb = 0, accc = 0;
+  bool fb = false, fc = false;
+  const int i_lo = imax(1, k0 - W + delta), i_hi = imin(L - kTurn - 3, k0 + kWave - 2); // i < L - kTurn - 2, i <= k - 1
+  for (int i = i_lo; i <= i_hi; i++) {
+    const int jend = imin(i + W, L);
+    // (closing pairs whose right range ends before the window and whose left ranges cannot reach it either are skipped:
+    // left ranges end at p - delta <= i + 1 + 30 - delta, right ranges at j - delta)
+    for (int j = i + kTurn + 3; j <= jend; j++) {
+      if (j - delta < k0 && i + 1 + kMaxLoop - delta < k0) continue;
+      const int type = ra_bp(lds, s[i], s[j]);
+      if (type == 0) continue;
+      const double bs = EM(b_stemend, i, j - 1);
+      if (bs == kNegInf) continue;
+      const int D = j - i;
+      const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
+      const int bi1 = s[i + 1], bj1 = s[j - 1];
+      for (int u1 = 0; u1 <= m; u1++) {
+        // lanes take the q of this p in the reference's order: q ascending <=> u2 descending
+        const int p = i + 1 + u1;
+        const int u2 = (m - u1) - lane;
+        bool valid = u2 >= 0 && !(u1 == 0 && u2 == 0);
+        double val = 0;
+        int q = 0;
+        if (valid) {
+          q = j - 1 - u2;
+          int type2 = ra_bp(lds, s[p], s[q]);
+          const double as = EM(a_stem, p - 1, q);
+          valid = type2 != 0 && as != kNegInf;
+          if (valid) {
+            type2 = ra_rtype(type2);
+            val = bs + ra_loop_energy_bf(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
+          }
+        }
+        unsigned long long mask = __ballot(valid);
+        const int kl1 = p - delta; // left range [i+1, p-delta]
+        const bool inl = k >= i + 1 && k <= kl1;
+        while (mask) {
+          const int src = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const double tv = __shfl(val, src);
+          const int tq = __shfl(q, src);
+          const int kr0 = tq + 1, kr1 = j - delta; // right range [q+1, j-delta]
+          const bool inr = k >= kr0 && k <= kr1;
+          if (inl || inr) {
+            const bool last = inl ? k == kl1 : k == kr1;
+            if (last) {
+              accb = fb ? ra_lse(lds, accb, tv) : tv;
+              fb = true;
+            } else {
+              accc = fc ? ra_lse(lds, accc, tv) : tv;
+              fc = true;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (k <= L) {
+    v.v(V_BP)[k - 1] = accb;
+    v.v(V_CBP)[k - 1] = accc;
+    v.v(V_BFLAG)[k - 1] = fb ? 1.0 : 0.0;
+    v.v(V_CFLAG)[k - 1] = fc ? 1.0 : 0.0;
+  }
+}
+
 template <int NS>
 __global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
@@ -1078,7 +1167,7 @@ __global__ __launch_bounds__(kBlock) void k_biloop(RaBatch b, RaConst c) {
   if (pf >= -690 && pf <= 690) { // raccess.cpp:500-507
     // large log Z: nearly always decided by the classification alone
     if (pf < 120.0 || !biloop_classify<NS>(lds, c, v, b.delta, lane)) biloop_run<false, NS>(lds, c, v, b.delta, lane);
-  } else {
+  } else if (b.logsum_windows == 0) { // (else: k_biloop_logsum, a wavefront per window of 64 positions)
     biloop_run<true, NS>(lds, c, v, b.delta, lane);
   }
 }
@@ -1222,6 +1311,10 @@ hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int
     hipLaunchKernelGGL(k_inside<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
     hipLaunchKernelGGL(k_outside<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
     hipLaunchKernelGGL(k_biloop<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  }
+  if (b.logsum_windows > 0) {
+    const int wblocks = (b.logsum_windows + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(k_biloop_logsum, dim3(wblocks, b.nseq), dim3(kBlock), 0, stream, b, c);
   }
   hipLaunchKernelGGL(k_access, dim3(blocks), dim3(kBlock), 0, stream, b, c);
   return hipGetLastError();

@@ -31,6 +31,9 @@ struct RaBatch {
   const unsigned char *codes;
   float *acc;  // out
   float *cond; // out
+  // > 0: the LOGSUM branch of the bulge / interior-loop sums is computed by k_biloop_logsum, a wavefront per window of
+  // 64 positions, this many windows per sequence (>= the longest sequence's); 0: by the ordered pass on the sequence's own wavefront
+  int32_t logsum_windows = 0;
 };
 
 // Enqueue fill + inside + outside + biloop + accessibility for a batch on `stream`.

@@ -94,3 +94,26 @@ def test_lengths_around_the_overflow_classification(ctx, oracle):
         oa, oc = oracle.raccess(s, 70, 5)
         assert np.array_equal(bits(acc), bits(oa)), len(s)
         assert np.array_equal(bits(cond), bits(oc)), len(s)
+
+
+def test_logsum_windows_match_the_ordered_pass(ctx, oracle, monkeypatch):
+    """The LOGSUM branch of the bulge / interior-loop sums (|log Z| > 690) is computed by a wavefront per window of 64
+    positions (k_biloop_logsum); PRB_RACCESS_LOGSUM_WINDOWS=0 keeps the ordered pass on the sequence's own wavefront.
+    Both bit-identical to the oracle: GC-rich sequences (in the branch from ~1,200 nt), lengths around window edges, a
+    sequence that is not in the branch in the same batch."""
+    rng = np.random.default_rng(23)
+    gc = lambda n: "".join(rng.choice(list("GGGCCCAU"), n))  # noqa: E731
+    seqs = [gc(2000), gc(1984), gc(1985), gc(2049), "".join(rng.choice(list("ACGU"), 700)), gc(2900)]
+    want = [oracle.raccess(s, 70, 5) for s in seqs]
+    _, _, t = oracle.raccess(seqs[0], 70, 5, debug=True)
+    assert t["alpha_outer"][-1] > 690
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("PRB_RACCESS_LOGSUM_WINDOWS", raising=False)
+        else:
+            monkeypatch.setenv("PRB_RACCESS_LOGSUM_WINDOWS", mode)
+        res = ctx.accessibility(seqs, 70, 5)
+        for s, (acc, cond), (oa, oc) in zip(seqs, res, want):
+            assert np.array_equal(bits(acc), bits(oa)), (mode, len(s))
+            assert np.array_equal(bits(cond), bits(oc)), (mode, len(s))
+    monkeypatch.delenv("PRB_RACCESS_LOGSUM_WINDOWS", raising=False)
