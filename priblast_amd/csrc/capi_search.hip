@@ -48,7 +48,7 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, listC, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
   // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
   // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
   // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
@@ -104,7 +104,7 @@ struct SearchWs {
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &listC, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
       b->release();
     front.release();
     if (copy_stream) {
@@ -1404,7 +1404,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // Wave-per-hit kernel with its state in HBM scratch, for the device list `cur` (indices into U;
   // nullptr = all) of m hits.  mode 0 writes G and retries hits that still overflow with a 4x
   // larger scratch; mode 2 writes base pairs at off_dev (indexed by list position).
-  auto run_wave = [&](int mode, const uint32_t *cur, int64_t m, uint32_t *spare, const int64_t *off_dev) -> int {
+  auto run_wave = [&](int mode, const uint32_t *cur, int64_t m, uint32_t *spare, const int64_t *off_dev, int handover = 0) -> int {
     int cap_diag = 512, cap_rec = 2048;
     if (mode != 0) { // caps known to suffice for every hit seen so far
       cap_diag = std::max(512, ctx->max_gap_caps);
@@ -1416,7 +1416,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = scratch_for(m, cap_diag, cap_rec, gs))) return rc;
       PRB_HIP(launch_gapped_wave(U, G, m, cur, qb->view, pd, sc, eo, gs, mode, mode == 0 ? w.overflow.as<uint8_t>() : nullptr,
                                  mode == 0 ? w.tierOf.as<uint8_t>() : nullptr, firstc,
-                                 mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream));
+                                 mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream, handover));
       if (mode != 0) break;
       int64_t again = 0;
       if ((rc = select_overflow(cur, m, other, &again))) return rc;
@@ -1468,12 +1468,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     int64_t m = nung;
     uint32_t *bufs[2] = {w.listA.as<uint32_t>(), w.listB.as<uint32_t>()};
     int nb = 0;
-    // In front of the cascade (gapped_front.hip; PRB_GAPPED_FRONT=0 leaves it out): the hits neither direction of which
-    // finds anything - four in five - are completed by a kernel that only has to prove that.  What it completes is
-    // reported as tier 0 (such a hit has no traced pairs: nothing is ever re-extended for it).
-    const char *fe = getenv("PRB_GAPPED_FRONT");
-    bool front_ran = false;
-    if (cascade[0] == 0 && !(fe && atoi(fe) == 0) && gapped_front_supported(sc, eo)) {
+    // the front kernel on the list (cur, m): what it completes leaves the list
+    auto run_front = [&]() -> int {
       if ((rc = w.frontScratch.ensure(gapped_front_scratch_bytes()))) return rc;
       if ((rc = ctx->time_begin())) return rc;
       PRB_HIP(launch_gapped_front(U, G, m, cur, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
@@ -1485,37 +1481,81 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       nb ^= 1;
       ctx->timers["gapped_front_hits"].launches += m - rest; // (a counter, not a time: hits completed by the front kernel)
       m = rest;
-      front_ran = true;
-      if ((rc = ctx->time_end("gapped_front", 1))) return rc;
-    }
+      return ctx->time_end("gapped_front", 1);
+    };
+    // the LDS tiers and the wavefront-per-hit kernel on the list (cur, m), each taking what the one before it could not hold
     const char *skip_env = getenv("PRB_GAPPED_SKIP_TIERS"); // experiment: bit t set = LDS tier t is left out behind the front kernel
-    const int skip_mask = (front_ran && skip_env) ? atoi(skip_env) : 0;
-    for (size_t c = 0; c < cascade.size() && m > 0; c++) {
-      const int tier = cascade[c];
-      if (tier < kLdsTiers - 1 && ((skip_mask >> tier) & 1)) continue;
-      if (tier == kWaveTier && front_free && !front_called) { // (see below: the longest extensions run nearly alone)
-        front_free();
-        front_called = true;
+    int skip_mask = 0;
+    auto run_cascade = [&](int handover) -> int {
+      for (size_t c = 0; c < cascade.size() && m > 0; c++) {
+        const int tier = cascade[c];
+        if (tier < kLdsTiers - 1 && ((skip_mask >> tier) & 1)) continue;
+        if (tier == kWaveTier && front_free && !front_called && !handover) { // (see below: the longest extensions run nearly alone)
+          front_free();
+          front_called = true;
+        }
+        if ((rc = ctx->time_begin())) return rc;
+        if (tier == kWaveTier) {
+          hs->slow_hits += m;
+          ctx->slow_hits += m;
+          if ((rc = run_wave(0, cur, m, bufs[nb], nullptr, handover))) return rc;
+          m = 0;
+        } else {
+          PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
+                                    firstc, w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
+                                    w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,
+                                    tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream, handover));
+          int64_t rest = 0;
+          if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
+          if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[tier %d%s] hits %lld, go on %lld\n", tier, handover ? ", first direction" : "", (long long)m, (long long)rest);
+          cur = bufs[nb];
+          nb ^= 1;
+          m = rest;
+        }
+        if ((rc = ctx->time_end(kTierTimer[tier], 1))) return rc;
       }
-      if ((rc = ctx->time_begin())) return rc;
-      if (tier == kWaveTier) {
-        hs->slow_hits += m;
-        ctx->slow_hits += m;
-        if ((rc = run_wave(0, cur, m, bufs[nb], nullptr))) return rc;
-        m = 0;
-      } else {
-        PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
-                                  firstc, w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
-                                  w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,
-                                  tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream));
-        int64_t rest = 0;
-        if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
-        if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[tier %d] hits %lld, go on %lld\n", tier, (long long)m, (long long)rest);
-        cur = bufs[nb];
-        nb ^= 1;
-        m = rest;
+      return PRB_OK;
+    };
+    // In front of the cascade (gapped_front.hip; PRB_GAPPED_FRONT=0 leaves it out): the hits neither direction of which
+    // finds anything - four in five - are completed by a kernel that only has to prove that.
+    const char *fe = getenv("PRB_GAPPED_FRONT");
+    const bool front_on = cascade[0] == 0 && !(fe && atoi(fe) == 0) && gapped_front_supported(sc, eo);
+    const char *he = getenv("PRB_GAPPED_HANDOVER");
+    const bool handover = front_on && !(he && atoi(he) == 0);
+    if (front_on) {
+      if ((rc = run_front())) return rc;
+      skip_mask = skip_env ? atoi(skip_env) : 0;
+    }
+    if (!handover) {
+      if ((rc = run_cascade(0))) return rc;
+    } else if (m > 0) {
+      // The hits that are left have a direction that finds something - or had too many cells for the front kernel.  Nine
+      // SECOND directions in ten still find nothing, and a tier pays for proving that what it pays for 16 anti-diagonals of
+      // any extension (8 - 40 ns per hit, against the front kernel's 0.6 per direction).  So the cascade first runs FIRST
+      // directions only (GapArgs::handover; a hit whose first direction the front kernel completed runs its second one, as
+      // ever), the front kernel then looks at the second directions of what the tiers stopped behind, and only the hits
+      // whose second direction finds something too come back to the cascade, for that direction.
+      const int64_t m1 = m;
+      if ((rc = w.listC.ensure((size_t)m1 * 4))) return rc;
+      PRB_HIP(hipMemcpyAsync(w.listC.p, cur, (size_t)m1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      if ((rc = run_cascade(1))) return rc;
+      // the hits an LDS tier or the wavefront-per-hit kernel stopped behind their first direction
+      PRB_HIP(launch_flag_marked(w.tierOf.as<uint8_t>(), w.listC.as<uint32_t>(), m1, kHandoverMark, w.overflow.as<uint8_t>(), ctx->stream));
+      cur = w.listC.as<uint32_t>();
+      m = m1;
+      int64_t mh = 0;
+      if ((rc = select_overflow(cur, m, bufs[nb], &mh))) return rc;
+      cur = bufs[nb];
+      nb ^= 1;
+      m = mh;
+      if (m > 0) {
+        if (rs[0].slot) { // (the hand-over slots of the first pass are not to be taken for this pass's)
+          PRB_HIP(hipMemsetAsync(w.resumeCount.p, 0, 16, ctx->stream));
+          PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 4 * 3, ctx->stream));
+        }
+        if ((rc = run_front())) return rc;
+        if ((rc = run_cascade(0))) return rc;
       }
-      if ((rc = ctx->time_end(kTierTimer[tier], 1))) return rc;
     }
   }
   return PRB_OK;

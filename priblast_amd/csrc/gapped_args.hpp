@@ -27,9 +27,6 @@ struct Rec32 {
   static __device__ __forceinline__ int da(word v) { return (v >> 27) & 7; }
 };
 
-// tier_out[x] of a hit that outgrew a kernel in direction 1: out.*[x] and bp_count[x] hold its state
-// after direction 0, so the next kernel of the cascade only has to extend the other direction
-constexpr uint8_t kResumeMark = 0x40;
 
 
 // Where a direction starts (gapped_extension.cpp:88-128), from the hit as the direction found it:
@@ -73,6 +70,7 @@ struct GapArgs {
   // mode 0: state dumps of hits that outgrow an LDS tier, for the next one to continue from
   // (slot[x] = -1: none): `rin` = what this kernel may continue, `rout` = where it leaves its own
   GapResume rin, rout;
+  int handover = 0; // mode 0, LDS tiers and the wavefront-per-hit kernel: stop behind a first direction that this kernel ran (kHandoverMark)
 };
 
 

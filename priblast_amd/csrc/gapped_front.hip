@@ -258,6 +258,8 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
     int64_t x = 0, qo = 0, dbase = 0;
     int query = 0, id = 0, qn = 1, q_sp = 0, db_sp = 0, q_len = 0, db_len = 0, id_start = 0;
     double e_tot = 0, e_acc = 0;
+    bool resumed = false;
+    int tier0 = 0, nleft0 = 0;
     if (live) {
       x = a.subset ? (int64_t)a.subset[w] : w;
       query = a.in.query[x];
@@ -272,12 +274,25 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
       id_start = a.in.db_id_start[x];
       e_tot = a.in.e_tot[x];
       e_acc = a.in.e_acc[x];
+      const uint8_t mark = a.tier_out[x];
+      if (is_resumed(mark)) { // the first direction is done already (an LDS tier stopped behind it): only the second one is looked at
+        resumed = true;
+        tier0 = mark & kMarkTier;
+        nleft0 = a.bp_count[x] & 0xFFFF;
+        q_sp = a.out.q_sp[x];
+        db_sp = a.out.db_sp[x];
+        q_len = a.out.q_len[x];
+        db_len = a.out.db_len[x];
+        id_start = a.out.db_id_start[x];
+        e_tot = a.out.e_tot[x];
+        e_acc = a.out.e_acc[x];
+      }
     }
     const uint8_t *qs = a.qb.enc + qo;
     const int q_start = f0 ? q_sp : q_sp + US(q_len) - 1;
     const int64_t db_start = f0 ? (int64_t)db_sp : (int64_t)db_sp + US(db_len) - 1;
     const int id_end = id_start + US(db_len) - 1;
-    bool dead = !live; // the direction is out of the proof: not there, improved, or too many cells
+    bool dead = !live || (resumed && f0); // the direction is out of the proof: not there, done already, improved, or too many cells
     FP_MARK(1);
 
     // ---- bases along both strands (:131-154 and GetChar) ----
@@ -513,7 +528,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
 
     FP_MARK(11);
     // ---- the hit: done when neither direction finds anything (GappedExtension::Run tail, :49-67) ----
-    const bool ok = live && !dead;
+    const bool ok = live && (!dead || (resumed && f0));
     const bool ok_other = __shfl_xor(ok ? 1 : 0, 1) != 0;
     double dng = 0;
     if (live) {
@@ -531,8 +546,8 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
         hy += d0;
         hy += d1;
         a.overflow[w] = 0;
-        a.tier_out[x] = (uint8_t)a.tier_id;
-        a.bp_count[x] = 0;
+        a.tier_out[x] = (uint8_t)(resumed ? tier0 : a.tier_id);
+        a.bp_count[x] = nleft0;
         a.out.q_sp[x] = q_sp;
         a.out.db_sp[x] = db_sp;
         a.out.q_len[x] = q_len;
@@ -545,7 +560,9 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
         a.out.e_tot[x] = e;
       } else {
         a.overflow[w] = 1;
-        if (ok) { // the first direction is done (it changes nothing): leave it for the next kernel, as the tiers do among themselves
+        if (resumed) {
+          a.tier_out[x] = (uint8_t)(kResumeMark | tier0); // (the second direction finds something: the cascade's, from where it stands)
+        } else if (ok) { // the first direction is done (it changes nothing): leave it for the next kernel, as the tiers do among themselves
           a.out.q_sp[x] = q_sp;
           a.out.db_sp[x] = db_sp;
           a.out.q_len[x] = q_len;

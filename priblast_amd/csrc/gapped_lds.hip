@@ -273,6 +273,7 @@ struct HitCtx {
   int diag_q, diag_d, diag_len, ndiag, nleft, nright;
   bool unsorted, ovf;
   bool resumed; // direction 0 was completed by an earlier kernel of the cascade: start at direction 1
+  int tier0;    // ... and the LDS tier that has room for it
 };
 // The scalars of one direction's recurrence (kept redundantly in every lane of the group).  Only
 // what cannot be had from the hit (HitCtx::h stays as the direction found it until dir_finish) and
@@ -1165,7 +1166,9 @@ template <int kMode> __device__ __forceinline__ void hit_load(const GapArgs &a, 
   c.nleft = 0;
   c.nright = 0;
   c.resumed = false;
-  if (kMode == 0 && a.tier_out[x] == kResumeMark) {
+  c.tier0 = 0;
+  if (kMode == 0 && is_resumed(a.tier_out[x])) {
+    c.tier0 = a.tier_out[x] & kMarkTier;
     h.q_sp = a.out.q_sp[x];
     h.db_sp = a.out.db_sp[x];
     h.q_len = a.out.q_len[x];
@@ -1237,11 +1240,11 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
       a.out.e_hyb[x] = h.e_tot - h.e_acc;
       a.out.e_tot[x] = h.e_tot;
       a.bp_count[x] = c.nleft;
-      a.tier_out[x] = kResumeMark;
+      a.tier_out[x] = (uint8_t)(kResumeMark | ((c.resumed ? c.tier0 : a.tier_id) & kMarkTier));
     }
     if (!c.ovf) {
       const int64_t x = c.x;
-      a.tier_out[x] = (uint8_t)a.tier_id;
+      a.tier_out[x] = (uint8_t)(a.tier_id > c.tier0 ? a.tier_id : c.tier0);
       a.bp_count[x] = c.nleft | (c.nright << 16);
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
       const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, c.qn, ds, a.pg.nchars);
@@ -1273,6 +1276,25 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
         t++;
       }
   }
+}
+
+// GapArgs::handover: the first direction is done, by this kernel; the hit is left for the front kernel's proof that the
+// second one finds nothing (the cascade's own business again only if it does find something).
+__device__ __forceinline__ void hit_handover(const GapArgs &a, int64_t w, const HitCtx &c, int gl) {
+  if (gl != 0) return;
+  const int64_t x = c.x;
+  const HitState &h = c.h;
+  a.overflow[w] = 0;
+  a.out.q_sp[x] = h.q_sp;
+  a.out.db_sp[x] = h.db_sp;
+  a.out.q_len[x] = h.q_len;
+  a.out.db_len[x] = h.db_len;
+  a.out.db_id_start[x] = h.id_start;
+  a.out.e_acc[x] = h.e_acc;
+  a.out.e_hyb[x] = h.e_tot - h.e_acc;
+  a.out.e_tot[x] = h.e_tot;
+  a.bp_count[x] = c.nleft;
+  a.tier_out[x] = (uint8_t)(kHandoverMark | (a.tier_id & kMarkTier));
 }
 
 // total base pairs of list entry w = complementary positions of the ungapped diagonal
@@ -1336,8 +1358,10 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
         hit_dir_done<kMode, true>(a, c, flag, og, r, S, gl);
         group_sync<true>();
         GP_MARK(7);
-        if (c.ovf || flag == 1) {
-          hit_store<kMode>(a, w, c, flag, gl);
+        const bool hand = kMode == 0 && a.handover && !c.ovf && flag == 0 && !c.resumed;
+        if (c.ovf || flag == 1 || hand) {
+          if (hand) hit_handover(a, w, c, gl);
+          else hit_store<kMode>(a, w, c, flag, gl);
           unsigned long long nw = 0;
           if (gl == 0) nw = (unsigned long long)ngroups + atomicAdd(a.next_work, 1ull);
           w = (int64_t)__shfl(nw, gbase);
@@ -1434,7 +1458,8 @@ template <int kMode, bool kInLds> __global__ __launch_bounds__(64) void k_gapped
   for (int64_t w = blockIdx.x; w < a.n; w += gridDim.x) {
     hit_load<kMode>(a, w, c);
     int last = 0;
-    for (int flag = c.resumed ? 1 : 0; flag < 2 && !c.ovf; flag++) {
+    bool hand = false;
+    for (int flag = c.resumed ? 1 : 0; flag < 2 && !c.ovf && !hand; flag++) {
       GP_MARK(8);
       dir_init<64, false>(a.sc, sb, c, flag, a.pg.seqs, a.pg.nchars, S, gl, a.o.delta, d);
       GP_MARK(0);
@@ -1446,9 +1471,11 @@ template <int kMode, bool kInLds> __global__ __launch_bounds__(64) void k_gapped
       hit_dir_done<kMode, false>(a, c, flag, og, r, S, gl);
       group_sync<false>();
       last = flag;
+      hand = kMode == 0 && a.handover && !c.ovf && flag == 0 && !c.resumed;
       GP_MARK(7);
     }
-    hit_store<kMode>(a, w, c, last, gl);
+    if (hand) hit_handover(a, w, c, gl);
+    else hit_store<kMode>(a, w, c, last, gl);
     GP_MARK(9);
   }
   prof.flush(kWaveTier * 2 + (kMode != 0));
@@ -1501,10 +1528,11 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
                              const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, const GapResume &rin,
-                             const GapResume &rout, hipStream_t s) {
+                             const GapResume &rout, hipStream_t s, int handover) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,   n,      subset, qb,        pg,         sc, o, overflow, tier_out, tier, first_flag, bp_count,
             trace,   bp_off, bp_out, next_work, rin,     rout};
+  a.handover = mode == 0 ? handover : 0;
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
   if (tier == 2) return launch_tier<Tier2, Rec32>(a, mode, s);
@@ -1514,10 +1542,11 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
-                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
+                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s, int handover) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, kWaveTier, first_flag, bp_count,
             nullptr, bp_off, bp_out, nullptr, GapResume{nullptr, nullptr, nullptr, 0}, GapResume{nullptr, nullptr, nullptr, 0}};
+  a.handover = mode == 0 ? handover : 0;
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a state block
   if (scratch.base == nullptr) { // state in LDS
     const size_t lds = scratch.bytes_per_thread;

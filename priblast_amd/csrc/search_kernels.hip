@@ -1123,6 +1123,18 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint4 *__restrict__ s
   dst[r * words + wi] = src[(int64_t)idx[r] * words + wi];
 }
 } // namespace
+namespace {
+__global__ __launch_bounds__(256) void k_flag_marked(const uint8_t *__restrict__ marks, const uint32_t *__restrict__ list, int64_t n, uint8_t mask,
+                                                     uint8_t *flags) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flags[i] = (marks[list[i]] & mask) ? 1 : 0;
+}
+} // namespace
+hipError_t launch_flag_marked(const uint8_t *marks, const uint32_t *list, int64_t n, uint8_t mask, uint8_t *flags, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_flag_marked, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, marks, list, n, mask, flags);
+  return hipGetLastError();
+}
 hipError_t launch_iota_u32(uint32_t *dst, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n);

@@ -132,6 +132,8 @@ hipError_t launch_pack_hits(const HitSoA &src, int64_t n, const int32_t *bp_coun
                             void *out, hipStream_t s);
 hipError_t launch_gather_u8(const uint8_t *src, const uint32_t *idx, uint8_t *dst, int64_t n, hipStream_t s);
 hipError_t launch_iota_u32(uint32_t *dst, int64_t n, hipStream_t s); // dst[i] = i
+// flags[i] = marks[list[i]] & mask != 0
+hipError_t launch_flag_marked(const uint8_t *marks, const uint32_t *list, int64_t n, uint8_t mask, uint8_t *flags, hipStream_t s);
 // dst row r = src row idx[r], rows of row_bytes (a multiple of 16) bytes
 hipError_t launch_gather_rows(const void *src, const uint32_t *idx, void *dst, int64_t n, int row_bytes, hipStream_t s);
 hipError_t launch_gather_hits(const HitSoA &src, const uint32_t *idx, HitSoA dst, int64_t n, hipStream_t s);
@@ -209,7 +211,7 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
                              const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work /* 8 bytes of scratch */,
-                             const GapResume &rin, const GapResume &rout, hipStream_t s);
+                             const GapResume &rin, const GapResume &rout, hipStream_t s, int handover = 0 /* GapArgs::handover */);
 // Trace slots: the extension pass (mode 0, LDS tiers) leaves the first kTraceCap cells (i | j << 8)
 // of each direction's traceback chain of hit x at trace[(2x + direction) * kTraceCap ...];
 // launch_bp_expand writes the base pairs of the final hits from them (hits of the wave kernel or
@@ -218,6 +220,16 @@ constexpr int kTraceCap = 32;
 // ids of the gapped kernels a hit can be completed by (tier_out): LDS tiers 0..3, then the
 // wavefront-per-hit kernel with its state in HBM scratch
 constexpr int kLdsTiers = 4, kWaveTier = 4;
+// tier_out[x] of a hit whose first direction is done and whose second one is somebody else's business: out.*[x] and
+// bp_count[x] hold its state after direction 0.  kResumeMark: the next kernel of the cascade extends the other
+// direction (a hit that outgrew a kernel in direction 1, or that the front kernel handed on with a first direction that
+// finds nothing).  kHandoverMark: an LDS tier stopped behind direction 0 on purpose (GapArgs::handover): the second
+// direction goes to the front kernel first - it finds nothing nine times in ten, which that kernel proves at a fraction of
+// a tier's cost.  The low three bits are the LDS tier that has room for the first direction: a hit is reported as the
+// larger of the tiers its two directions needed (the tier that would have to extend it again for its pairs).
+constexpr uint8_t kResumeMark = 0x40, kHandoverMark = 0x80, kMarkTier = 0x07;
+__host__ __device__ inline bool is_resumed(uint8_t t) { return (t & (kResumeMark | kHandoverMark)) != 0; }
+
 // launch_gapped_front (gapped_front.hip): the kernel in front of the cascade.  It proves that a direction finds nothing
 // within its `-x` anti-diagonals (phases that are dense over directions / filled cells / (cell, candidate) pairs of 64
 // directions at a time) and completes the hits whose two directions both find nothing; the others are flagged in
@@ -238,6 +250,6 @@ hipError_t launch_bp_ends(const int64_t *bp_off, int64_t n, const int32_t *bp, i
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
-                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
+                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s, int handover = 0);
 
 } // namespace prb

@@ -162,14 +162,16 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
-                                 "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_CHUNK_HITS=37", "PRB_GAPPED_CHUNK_HITS=500,PRB_TRACE_SLOT_CAP=1", "PRB_GAPPED_FRONT=0", "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=1", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
+                                 "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_HANDOVER=0", "PRB_GAPPED_HANDOVER=0,PRB_GAPPED_NO_RESUME", "PRB_GAPPED_RESUME_CAP", "PRB_GAPPED_CHUNK_HITS=37", "PRB_GAPPED_CHUNK_HITS=500,PRB_TRACE_SLOT_CAP=1", "PRB_GAPPED_FRONT=0", "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=1", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
                                  "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
     LDS kernel (normally only the extensions that outgrow the smaller tiers) must give the same
     final hits and pairs as the default cascade (tiers 0 -> 1 -> 2 -> 3 -> wave), and so must the
     cascade without the kernel in front of it that completes the hits whose two directions find nothing
-    (PRB_GAPPED_FRONT=0; the default has it), and with the gapped stage run in chunks of a few hits (PRB_GAPPED_CHUNK_HITS,
+    (PRB_GAPPED_FRONT=0; the default has it), without the tiers stopping behind a first direction so that the front kernel
+    can look at the second one (PRB_GAPPED_HANDOVER=0), with hand-over pools that run out (PRB_GAPPED_RESUME_CAP=1), and with
+    the gapped stage run in chunks of a few hits (PRB_GAPPED_CHUNK_HITS,
     also with the final hits' pairs from a second extension: the kept lists are what that reads); likewise re-extending the final
     hits (all, or those with more than one traced pair per side) instead of reading their
     base pairs from the trace slots of the extension pass; likewise the general four-key sort
