@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(ROOT, "lib", "libpriblast_hip.so")
+LIB_PATH = os.environ.get("PRB_LIB_PATH") or os.path.join(ROOT, "lib", "libpriblast_hip.so")  # (PRB_LIB_PATH: developer builds)
 BIN_PATH = os.path.join(ROOT, "bin", "pRIblast-hip")
 PARAMS = os.path.join(ROOT, "params", "rna_andronescu2007.par")
 

@@ -61,7 +61,10 @@ __device__ unsigned long long g_front_prof[32];
 namespace {
 
 constexpr int kFD = kFrontMaxDrop; // anti-diagonals covered: the largest -x this kernel takes
-constexpr int kFR = 24;            // cells per direction, the start included
+#ifndef PRB_FRONT_RING
+#define PRB_FRONT_RING 24
+#endif
+constexpr int kFR = PRB_FRONT_RING;            // cells per direction, the start included
 constexpr int kFWaves = 1;         // wavefronts per workgroup: one
 // Directions per wavefront.  The per-direction phases leave the lanes beyond them idle, the pooled phases use all 64; a
 // wavefront's time is the latency of its chain of phases (LDS and L2 round trips), so what counts is how many wavefronts a
