@@ -303,6 +303,10 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
       const char *e = std::getenv("PRB_RACCESS_LOGSUM_WINDOWS"); // 0: the ordered pass on the sequence's own wavefront (tests)
       const int64_t lmax = len(order[pos]);                         // (longest first)
       b.logsum_windows = (e && std::atoi(e) == 0) ? 0 : (int32_t)((lmax + 63) / 64);
+      // helper wavefronts for the big folds when the launch leaves most of the GPU idle anyway (three workgroups of three
+      // wavefronts fit a compute unit); PRB_RACCESS_HELPERS = 0 / 1 / 2 says otherwise
+      const char *h = std::getenv("PRB_RACCESS_HELPERS");
+      b.helpers = h ? std::max(0, std::min(2, std::atoi(h))) : (n <= 512 ? 2 : 0);
     }
     if ((rc = ctx->time_begin())) return rc;
     PRB_HIP(ra_launch(b, ctx->ra_const, band, vec, ctx->stream));

@@ -46,6 +46,7 @@ __device__ unsigned long long g_ra_prof[32];
 
 constexpr int kWave = 64;
 constexpr int kRaAhead = 8; // interior-loop terms fetched ahead of the fold in k_inside / k_outside
+constexpr int kHB = 8;      // ... per batch when helper wavefronts prepare them (a barrier per batch: fewer, longer rounds)
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
 
@@ -168,18 +169,28 @@ __global__ void k_fill(double *p, int64_t n, double value) {
 }
 
 // ------------------------------------------------------------------------------ inside
-template <int NP>
-__global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
+// kH = 0: a wavefront per sequence, four sequences per workgroup (throughput: thousands of sequences side by side).
+// kH = 1, 2: a WORKGROUP per sequence - its first wavefront owns the sequence as before, the others are helpers for the
+// one phase that is 35 % of a pass, the big fold: they walk the same row masks (the iterator is integer work, every
+// wavefront runs it and so knows without a word how many rounds there are), evaluate the terms of the NEXT batch of eight -
+// fetch, loop energies - into LDS while the owner folds the batch before; a workgroup barrier per batch.  The fold order
+// is untouched.  For the few sequences of a query batch, whose time is the latency of one wavefront's chain.
+template <int NP, int kH>
+__global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_inside(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
-  __shared__ RowMasks rowmasks[kWavesPerBlock];
+  __shared__ RowMasks rowmasks[kH ? 1 : kWavesPerBlock];
+  __shared__ double xbuf[kH ? 2 : 1][kHB][kH ? kWave : 1]; // kH > 0: the terms of two batches, [batch & 1][term][lane]
+  __shared__ int xflag[2];                                       // ... and whether there is a batch after them
   ra_load_lds(lds, c);
   const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (idx >= b.nseq) return;
-  RowMasks &rm = rowmasks[threadIdx.x >> 6]; // rows of Alpha_stem
+  const int role = kH ? (int)(threadIdx.x >> 6) : 0; // 0: the sequence's own wavefront
+  const int idx = kH ? (int)blockIdx.x : (int)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (idx >= b.nseq) return; // (kH > 0: the whole workgroup)
+  RowMasks &rm = rowmasks[kH ? 0 : (threadIdx.x >> 6)]; // rows of Alpha_stem
   RA_PROF_DECL;
-  const bool use_masks = b.W + 2 + kMaxLoop <= 128; // spans <= W + 1 fit a mask, live rows <= W + 2 + MAXLOOP fit the ring
-  for (int t = lane; t < 128; t += kWave) rowmask_clear(rm, t);
+  const bool use_masks = b.W + 2 + kMaxLoop <= 128; // spans <= W + 1 fit a mask, live rows <= W + 2 + MAXLOOP fit the ring (kH > 0: the host made sure)
+  if (role == 0)
+    for (int t = lane; t < 128; t += kWave) rowmask_clear(rm, t);
   using SL = RaSmallLayout;
   const SeqView v = make_view(b, idx);
   const int L = v.L, W = v.W, S = v.S;
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
     // lane mapping: d = dtop - lane, dtop = dmax, dmax-64, ...  (the last pass holds the
     // small spans, which are the cheap ones in every inside phase)
     const int dmax = imin(j, W + 1);
+    if (role == 0) { // ---- phases 1 - 3: the sequence's own wavefront ----
     if (lane == 0) rowmask_clear(rm, j - 2); // the row that gets its first cell in column j + 1
 
     // phase 1: Alpha_stem (raccess.cpp:102-129) and Alpha_multi2 (:145-162): both need only
@@ -316,12 +328,109 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
     }
     wave_sync();
     RA_PROF(3);
+    } // role == 0
 
     // phase 4: Alpha_stemend (:193-226).  The enclosed stems (p = i + u1, q = j - u2) are folded in the
     // reference's order - p ascending, q ascending - by the lane that owns the cell; a lane walks only the
     // terms that exist (set bits of the rows of Alpha_stem, spans max(5, d - 30) .. d - u1), eight at a time:
     // their band entries and sequence codes are fetched together, then folded one by one.
-    if (j != L && use_masks) {
+    if constexpr (kH > 0) {
+      __syncthreads(); // the owner's phases 1 - 3 (Alpha_stem, the row masks) before the helpers read them
+      if (j != L) {
+        const int bj = s[j];
+        for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
+          const int d = dtop - lane;
+          const bool cell = d >= kTurn;
+          const int i = cell ? j - d : 0;
+          const int type = cell ? ra_bp(lds, s[i], s[j + 1]) : 0;
+          const int bi1 = cell ? s[i + 1] : 0;
+          double temp = type != 0 ? ra_hairpin_energy(lds, type, d, bi1, bj) : 0.0;
+          const int m = type != 0 ? imin(kMaxLoop, d - (kTurn + 2)) : -1;
+          const int span_lo = imax(kTurn + 2, d - kMaxLoop);
+          int u1 = -1;
+          uint32_t wbits = 0;
+          bool more = m >= 0;
+          // which terms (every wavefront, identically: integer work on the row masks in LDS)
+          auto advance = [&](int (&su1)[kHB], int (&sspan)[kHB]) {
+#pragma unroll
+            for (int t = 0; t < kHB; t++) {
+              const bool adv = more && wbits == 0 && u1 < m;
+              u1 += adv ? 1 : 0;
+              const uint32_t wnew = rowmask_window(rm, i + (u1 < 0 ? 0 : u1), span_lo, d - u1 - (u1 == 0 ? 1 : 0));
+              wbits = adv ? wnew : wbits;
+              const bool has = more && wbits != 0;
+              sspan[t] = span_lo + __builtin_ctz(wbits | 0x80000000u);
+              su1[t] = has ? u1 : -1;
+              wbits = has ? (wbits & (wbits - 1)) : wbits;
+              more = more && (wbits != 0 || u1 < m);
+            }
+          };
+          // their values, terms [t0, t1) of the batch, into xbuf[buf] (a helper)
+          auto values = [&](const int (&su1)[kHB], const int (&sspan)[kHB], int t0, int t1, int buf) {
+            double sts[kHB];
+            int su2[kHB], sq[kHB], sq1[kHB], sp0[kHB], sp1[kHB];
+#pragma unroll
+            for (int t = 0; t < kHB; t++) {
+              if (t < t0 || t >= t1) continue;
+              const bool ok = su1[t] >= 0;
+              const int p = ok ? i + su1[t] : i, q = ok ? p + sspan[t] : j;
+              su2[t] = j - q;
+              sts[t] = EM(a_stem, p, q);
+              sq[t] = s[q];
+              sq1[t] = s[q + 1];
+              sp0[t] = s[p];
+              sp1[t] = s[p + 1];
+            }
+#pragma unroll
+            for (int t = 0; t < kHB; t++) {
+              if (t < t0 || t >= t1) continue;
+              const int type2 = ra_rtype(ra_bp(lds, sp1[t], sq[t]));
+              const double z = ra_loop_energy_bf(lds, c.big, type, type2, su1[t] < 0 ? 0 : su1[t], su2[t], bi1, bj, sp0[t], sq1[t]);
+              xbuf[buf][t][lane] = (su1[t] >= 0 && sts[t] != kNegInf && type2 != 0) ? sts[t] + z : kNegInf;
+            }
+          };
+          // (is there another batch?  Before the first: every wavefront sees it from the cells themselves; from then on
+          // the first helper says so - the owner does not walk the masks at all, its rounds are the fold alone)
+          bool pend = __ballot(more) != 0;
+          for (int r = 0;; r++) {
+            if (pend && role != 0) {
+              int su1[kHB], sspan[kHB];
+              advance(su1, sspan);
+              if (kH == 1) {
+                values(su1, sspan, 0, kHB, r & 1);
+              } else {
+                if (role == 1) values(su1, sspan, 0, kHB / 2, r & 1);
+                if (role == 2) values(su1, sspan, kHB / 2, kHB, r & 1);
+              }
+              const bool nxt = __ballot(more) != 0; // (every lane of the helper takes part)
+              if (role == 1 && lane == 0) xflag[(r + 1) & 1] = nxt ? 1 : 0;
+            }
+            if (role == 0 && r >= 1) { // the fold, one batch behind
+#pragma unroll
+              for (int t = 0; t < kHB; t++) {
+                const double x = xbuf[(r - 1) & 1][t][lane];
+                const double rr = ra_lse(lds, temp, x);
+                temp = x != kNegInf ? rr : temp;
+              }
+            }
+            __syncthreads();
+            if (!pend) break;
+            pend = xflag[(r + 1) & 1] != 0;
+          }
+          if (role == 0 && cell) {
+            double out = kNegInf;
+            if (type != 0) {
+              const int tt = ra_rtype(type);
+              out = ra_lse(lds, temp,
+                           EM(a_multi, i, j) + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + bi1] +
+                               lds.small[SL::kDangle5 + tt * 5 + bj]);
+            }
+            EM(a_stemend, i, j) = out;
+          }
+        }
+      }
+    }
+    if (kH == 0 && j != L && use_masks) {
       const int bj = s[j]; // = s[j'-1] for the closing pair (i, j' = j+1)
       for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
         const int d = dtop - lane;
@@ -404,7 +513,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
         }
       }
     }
-    if (j != L && !use_masks) {
+    if (kH == 0 && j != L && !use_masks) {
       // (spans beyond the row masks: every (u1, u2) term of the window is enumerated wave-uniformly)
       const int bj = s[j]; // = s[j'-1] for the closing pair (i, j' = j+1)
       for (int dtop = dmax; dtop >= kTurn; dtop -= kWave) {
@@ -467,18 +576,23 @@ __global__ __launch_bounds__(kBlock, 3) void k_inside(RaBatch b, RaConst c) {
 }
 
 // ----------------------------------------------------------------------------- outside
-template <int NP>
-__global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
+// (kH: helper wavefronts for the big fold, see k_inside)
+template <int NP, int kH>
+__global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_outside(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
-  __shared__ RowMasks rowmasks[kWavesPerBlock];
+  __shared__ RowMasks rowmasks[kH ? 1 : kWavesPerBlock];
+  __shared__ double xbuf[kH ? 2 : 1][kHB][kH ? kWave : 1];
+  __shared__ int xflag[2];
   ra_load_lds(lds, c);
   const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int role = kH ? (int)(threadIdx.x >> 6) : 0;
+  const int idx = kH ? (int)blockIdx.x : (int)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
   if (idx >= b.nseq) return;
   RA_PROF_DECL;
-  RowMasks &rm = rowmasks[threadIdx.x >> 6]; // rows of Beta_stemend
+  RowMasks &rm = rowmasks[kH ? 0 : (threadIdx.x >> 6)]; // rows of Beta_stemend
   const bool use_masks = b.W + 2 + kMaxLoop <= 128;
-  for (int t = lane; t < 128; t += kWave) rowmask_clear(rm, t);
+  if (role == 0)
+    for (int t = lane; t < 128; t += kWave) rowmask_clear(rm, t);
   using SL = RaSmallLayout;
   const SeqView v = make_view(b, idx);
   const int L = v.L, W = v.W, S = v.S;
@@ -512,6 +626,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
     // spans, which are the cheap ones in every outside phase)
     const int dmax = imin(q, W + 1);
 
+    if (role == 0) { // ---- phases A - D: the sequence's own wavefront ----
     // phase A: Beta_stemend (:278-279), copy from column q+1
     if (use_masks && lane == 0) rowmask_clear(rm, q - W); // the row whose first cell comes in column q - 1 (spans >= W never exist)
     // Also, in registers for the chains of phase B: per cell the term it contributes to Beta_multi (:296-300), and
@@ -666,6 +781,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
       RA_PROF(11);
     }
 
+    } // role == 0
+    if constexpr (kH > 0) __syncthreads(); // the owner's phases A - D (Beta_stemend, the row masks) before the helpers read them
+
     // phase E: Beta_stem (:367-409).  Enclosing pairs (i = p - u1, j+1 = q + u2 + 1) in the reference's
     // order: i ascending, j ascending.  As in k_inside's phase 4, a lane walks only the terms whose
     // Beta_stemend entry exists (set bits of a window of the row masks), eight at a time: fetch, evaluate, fold.
@@ -684,6 +802,78 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
         uint32_t wbits = 0;
         int span0 = 0; // span of bit 0 of wbits
         bool more = t2raw != 0 && u1 > 0;
+        if constexpr (kH > 0) {
+          // which terms (every wavefront of the workgroup, identically)
+          auto advance = [&](int (&su1)[kHB], int (&sspan)[kHB]) {
+#pragma unroll
+            for (int t = 0; t < kHB; t++) {
+              const bool adv = more && wbits == 0 && u1 > 0;
+              u1 -= adv ? 1 : 0;
+              const int u2max = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - d - u1);
+              const int s0 = d + u1 + (u1 == 0 ? 1 : 0); // (i, j) == (p, q) is excluded (:377)
+              const uint32_t wnew = rowmask_window(rm, p - u1, s0, d + u1 + u2max);
+              wbits = adv ? wnew : wbits;
+              span0 = adv ? s0 : span0;
+              const bool has = more && wbits != 0;
+              sspan[t] = span0 + __builtin_ctz(wbits | 0x80000000u);
+              su1[t] = has ? u1 : -1;
+              wbits = has ? (wbits & (wbits - 1)) : wbits;
+              more = more && (wbits != 0 || u1 > 0);
+            }
+          };
+          // their values, terms [t0, t1) of the batch, into xbuf[buf] (a helper)
+          auto values = [&](const int (&su1)[kHB], const int (&sspan)[kHB], int t0, int t1, int buf) {
+            double ses[kHB];
+            int su2[kHB], sj[kHB], sj1[kHB], si0[kHB], si1[kHB];
+#pragma unroll
+            for (int t = 0; t < kHB; t++) {
+              if (t < t0 || t >= t1) continue;
+              const bool ok = su1[t] >= 0;
+              const int i = ok ? p - su1[t] : p, j = ok ? i + sspan[t] : q; // (a lane without a term reads its own cell)
+              su2[t] = j - q;
+              ses[t] = EM(b_stemend, i, j);
+              sj[t] = s[j];
+              sj1[t] = s[j + 1];
+              si0[t] = s[i];
+              si1[t] = s[i + 1];
+            }
+#pragma unroll
+            for (int t = 0; t < kHB; t++) {
+              if (t < t0 || t >= t1) continue;
+              const int type = ra_bp(lds, si0[t], sj1[t]);
+              const double z = ra_loop_energy_bf(lds, c.big, type, type2, su1[t] < 0 ? 0 : su1[t], su2[t], si1[t], sj[t], bp0, bq1);
+              xbuf[buf][t][lane] = (su1[t] >= 0 && ses[t] != kNegInf && type != 0) ? ses[t] + z : kNegInf;
+            }
+          };
+          // (is there another batch?  Before the first: every wavefront sees it from the cells themselves; from then on
+          // the first helper says so - the owner does not walk the masks at all, its rounds are the fold alone)
+          bool pend = __ballot(more) != 0;
+          for (int r = 0;; r++) {
+            if (pend && role != 0) {
+              int su1[kHB], sspan[kHB];
+              advance(su1, sspan);
+              if (kH == 1) {
+                values(su1, sspan, 0, kHB, r & 1);
+              } else {
+                if (role == 1) values(su1, sspan, 0, kHB / 2, r & 1);
+                if (role == 2) values(su1, sspan, kHB / 2, kHB, r & 1);
+              }
+              const bool nxt = __ballot(more) != 0; // (every lane of the helper takes part)
+              if (role == 1 && lane == 0) xflag[(r + 1) & 1] = nxt ? 1 : 0;
+            }
+            if (role == 0 && r >= 1) { // the fold, one batch behind
+#pragma unroll
+              for (int t = 0; t < kHB; t++) {
+                const double x = xbuf[(r - 1) & 1][t][lane];
+                const double rr = ra_lse(lds, temp, x);
+                temp = x != kNegInf ? rr : temp;
+              }
+            }
+            __syncthreads();
+            if (!pend) break;
+            pend = xflag[(r + 1) & 1] != 0;
+          }
+        } else {
         // (as in k_inside's phase 4: which terms, without a branch; fetch; values - then the fold one batch behind)
         auto next_batch = [&](double (&xs)[kRaAhead]) {
           int su1[kRaAhead], sspan[kRaAhead];
@@ -738,6 +928,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
           for (int t = 0; t < kRaAhead; t++) xs[t] = xn[t];
           pending = again;
         }
+        } // kH == 0
       } else {
         // (spans beyond the row masks: every (u1, u2) term of the window is enumerated wave-uniformly)
         // j - i = d + u1 + u2 <= W + 1; the pass bound uses dbot
@@ -792,14 +983,14 @@ __global__ __launch_bounds__(kBlock, 3) void k_outside(RaBatch b, RaConst c) {
             out = ra_lse(lds, x, out);
           }
         }
-        EM(b_stem, p, q) = out;
+        if (role == 0) EM(b_stem, p, q) = out;
       }
     }
     wave_sync();
     RA_PROF(12);
   }
   // remaining Beta_outer positions (columns stop at q = 4)
-  if (lane == 1)
+  if (role == 0 && lane == 1)
     for (int i = (L >= kTurn + 1 ? kTurn - 1 : L - 1); i >= 0; i--) beta_outer_at(i);
 }
 
@@ -1304,12 +1495,24 @@ hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int
   // cells of a column (spans 3 .. W + 1) and terms of Beta_outer (W + 1) per pass of 64 lanes: two passes up to a
   // maximal span of 127 (the default is 70), four up to kRaMaxSpan
   if (b.W + 1 <= 128) {
-    hipLaunchKernelGGL(k_inside<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
-    hipLaunchKernelGGL(k_outside<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    // Few sequences (a batch of queries): a workgroup per sequence, helper wavefronts for the big folds - the time is one
+    // wavefront's chain, the GPU otherwise idle.  Many (a database): a wavefront per sequence, as many side by side as fit.
+    const int helpers = b.helpers >= 0 ? b.helpers : 0;
+    const bool masks = b.W + 2 + kMaxLoop <= 128;
+    if (helpers == 2 && masks) {
+      hipLaunchKernelGGL((k_inside<2, 2>), dim3(b.nseq), dim3(kWave * 3), 0, stream, b, c);
+      hipLaunchKernelGGL((k_outside<2, 2>), dim3(b.nseq), dim3(kWave * 3), 0, stream, b, c);
+    } else if (helpers == 1 && masks) {
+      hipLaunchKernelGGL((k_inside<2, 1>), dim3(b.nseq), dim3(kWave * 2), 0, stream, b, c);
+      hipLaunchKernelGGL((k_outside<2, 1>), dim3(b.nseq), dim3(kWave * 2), 0, stream, b, c);
+    } else {
+      hipLaunchKernelGGL((k_inside<2, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
+      hipLaunchKernelGGL((k_outside<2, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    }
     hipLaunchKernelGGL(k_biloop<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
   } else {
-    hipLaunchKernelGGL(k_inside<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
-    hipLaunchKernelGGL(k_outside<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL((k_inside<4, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL((k_outside<4, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
     hipLaunchKernelGGL(k_biloop<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
   }
   if (b.logsum_windows > 0) {

@@ -34,6 +34,9 @@ struct RaBatch {
   // > 0: the LOGSUM branch of the bulge / interior-loop sums is computed by k_biloop_logsum, a wavefront per window of
   // 64 positions, this many windows per sequence (>= the longest sequence's); 0: by the ordered pass on the sequence's own wavefront
   int32_t logsum_windows = 0;
+  // helper wavefronts per sequence for the big folds of the inside / outside passes (0, 1 or 2): a workgroup per sequence
+  // instead of a wavefront - for the few sequences of a query batch, whose time is the latency of one wavefront's chain
+  int32_t helpers = 0;
 };
 
 // Enqueue fill + inside + outside + biloop + accessibility for a batch on `stream`.

@@ -117,3 +117,21 @@ def test_logsum_windows_match_the_ordered_pass(ctx, oracle, monkeypatch):
             assert np.array_equal(bits(acc), bits(oa)), (mode, len(s))
             assert np.array_equal(bits(cond), bits(oc)), (mode, len(s))
     monkeypatch.delenv("PRB_RACCESS_LOGSUM_WINDOWS", raising=False)
+
+
+@pytest.mark.parametrize("helpers", ["0", "1", "2"])
+def test_helper_wavefronts_do_not_change_a_bit(ctx, oracle, monkeypatch, helpers):
+    """PRB_RACCESS_HELPERS: the big folds of the inside / outside passes with 0, 1 or 2 helper wavefronts per sequence
+    (a workgroup per sequence; the default for batches of up to 512 sequences is 2) - ragged batch, both passes over the
+    cells of a column (W = 70: 69 cells), a span that leaves the row masks (W = 100: helpers do not apply) - bit-identical
+    to the oracle."""
+    monkeypatch.setenv("PRB_RACCESS_HELPERS", helpers)
+    rng = np.random.default_rng(31)
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in (5, 64, 71, 300, 777)] + ["GGGGGCCAAAAGGCCCCCAUAU" * 9, ""]
+    for W, delta in ((70, 5), (40, 7), (100, 5)):
+        res = ctx.accessibility(seqs, W, delta)
+        for s, (acc, cond) in zip(seqs, res):
+            oa, oc = oracle.raccess(s, W, delta) if len(s) else (np.zeros(0, np.float32), np.zeros(0, np.float32))
+            assert np.array_equal(bits(acc), bits(oa)), (helpers, W, len(s))
+            assert np.array_equal(bits(cond), bits(oc)), (helpers, W, len(s))
+    monkeypatch.delenv("PRB_RACCESS_HELPERS", raising=False)
