@@ -290,6 +290,7 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
     RaBatch b;
     b.desc = ctx->ra_desc.as<RaSeqDesc>();
     b.nseq = n;
+    b.lmax = (int32_t)len(order[pos]); // (longest first)
     b.W = W;
     b.delta = delta;
     b.band = ctx->ra_band.as<double>();
@@ -307,6 +308,8 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
       // wavefronts fit a compute unit); PRB_RACCESS_HELPERS = 0 / 1 / 2 says otherwise
       const char *h = std::getenv("PRB_RACCESS_HELPERS");
       b.helpers = h ? std::max(0, std::min(2, std::atoi(h))) : (n <= 512 ? 2 : 0);
+      const char *wa = std::getenv("PRB_RACCESS_WINDOWS_ALL"); // (tests: 0 / 1 whatever the size of the launch)
+      b.windows_all = wa ? (std::atoi(wa) != 0) : (n <= 512);
     }
     if ((rc = ctx->time_begin())) return rc;
     PRB_HIP(ra_launch(b, ctx->ra_const, band, vec, ctx->stream));

@@ -1265,19 +1265,11 @@ __device__ bool biloop_classify(const RaLds &lds, const RaConst &c, const SeqVie
 // evaluating the tuples of one (i, j, u1) side by side, as above -, and a lane folds a tuple in only if its position lies
 // in one of the tuple's two ranges.  Every window costs what ~(W + 64) values of i cost, all windows of all sequences
 // run at once: the time of a sequence no longer grows with its length.
-__global__ __launch_bounds__(kBlock) void k_biloop_logsum(RaBatch b, RaConst c) {
-  __shared__ RaLds lds;
-  const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.y;
-  const SeqView v = make_view(b, idx);
-  const int L = v.L, W = v.W, S = v.S, delta = b.delta;
-  const double pf = v.v(V_AO)[L];
-  // (both tests are the same for every thread of the workgroup: nobody is left waiting at the barrier of the table load)
-  if (pf >= -690 && pf <= 690) return; // the linear branch: k_biloop
-  if (1 + kWave * (int)(blockIdx.x * kWavesPerBlock) > L) return;
-  ra_load_lds(lds, c);
-  const int k0 = 1 + kWave * (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-  if (k0 > L) return;
+// (kLogSum false: the linear branch, the same walk with plain sums of expd(e) - for the windows the classification below
+// cannot decide, and for sequences with log Z < 120)
+template <bool kLogSum>
+__device__ void biloop_window(const RaLds &lds, const RaConst &c, const SeqView &v, int delta, int lane, int k0) {
+  const int L = v.L, W = v.W, S = v.S;
   const int k = k0 + lane; // this lane's position
   const unsigned char *s = v.s;
   const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
@@ -1311,7 +1303,8 @@ __global__ __launch_bounds__(kBlock) void k_biloop_logsum(RaBatch b, RaConst c) 
           valid = type2 != 0 && as != kNegInf;
           if (valid) {
             type2 = ra_rtype(type2);
-            val = bs + ra_loop_energy_bf(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
+            const double e = bs + ra_loop_energy_bf(lds, c.big, type, type2, u1, u2, bi1, bj1, s[p - 1], s[q + 1]) + as;
+            val = kLogSum ? e : ra_expd(lds, e);
           }
         }
         unsigned long long mask = __ballot(valid);
@@ -1326,7 +1319,10 @@ __global__ __launch_bounds__(kBlock) void k_biloop_logsum(RaBatch b, RaConst c) 
           const bool inr = k >= kr0 && k <= kr1;
           if (inl || inr) {
             const bool last = inl ? k == kl1 : k == kr1;
-            if (last) {
+            if (!kLogSum) {
+              if (last) accb += tv;
+              else accc += tv;
+            } else if (last) {
               accb = fb ? ra_lse(lds, accb, tv) : tv;
               fb = true;
             } else {
@@ -1343,6 +1339,136 @@ __global__ __launch_bounds__(kBlock) void k_biloop_logsum(RaBatch b, RaConst c) 
     v.v(V_CBP)[k - 1] = accc;
     v.v(V_BFLAG)[k - 1] = fb ? 1.0 : 0.0;
     v.v(V_CFLAG)[k - 1] = fc ? 1.0 : 0.0;
+  }
+}
+
+// biloop_classify for a window of 64 positions (one per lane): the flags are order-independent ORs, so a window only
+// has to look at the closing pairs whose ranges can reach it.  Stores +inf / 0 where that decides a position's sums and
+// returns false when some position of the window needs its true sums.
+__device__ bool biloop_classify_window(const RaLds &lds, const RaConst &c, const SeqView &v, int delta, int lane, int k0) {
+  const int L = v.L, W = v.W, S = v.S;
+  const int k = k0 + lane;
+  const unsigned char *s = v.s;
+  const double *a_stem = v.tab(A_STEM), *b_stemend = v.tab(B_STEMEND);
+  unsigned fl = 0; // bit 0 b-big, 1 b-nonzero, 2 c-big, 3 c-nonzero
+  const int i_lo = imax(1, k0 - W + delta), i_hi = imin(L - kTurn - 3, k0 + kWave - 2);
+  for (int i = i_lo; i <= i_hi; i++) {
+    const int jend = imin(i + W, L);
+    for (int jb = i + kTurn + 3; jb <= jend; jb += kWave) {
+      const int jl = jb + lane;
+      const int typ_l = jl <= jend ? ra_bp(lds, s[i], s[jl]) : 0;
+      const double bs_l = typ_l != 0 ? EM(b_stemend, i, jl - 1) : kNegInf;
+      // (pairs that cannot reach the window: right ranges end at j - delta, left ranges at i + 1 + 30 - delta at the latest)
+      unsigned long long jmask = __ballot(typ_l != 0 && bs_l != kNegInf && !(jl - delta < k0 && i + 1 + kMaxLoop - delta < k0));
+      while (jmask) {
+        const int jt = __builtin_ctzll(jmask);
+        jmask &= jmask - 1;
+        const int j = jb + jt;
+        const int type = __builtin_amdgcn_readlane(typ_l, jt);
+        const double bs = readlane_f64(bs_l, jt);
+        const int D = j - i;
+        const int m = imin(kMaxLoop, D - 6); // u1 + u2 <= m
+        const int bi1 = s[i + 1], bj1 = s[j - 1];
+        const int kr1 = j - delta;
+        unsigned long long col_nz = 0, col_big = 0; // bit = q - (j - 1 - m)
+        unsigned row_nz = 0, row_big = 0;           // bit = u1
+        const int nslots = 1 + (m + 1) / 2;         // (0), (1, m), (2, m - 1), ... (see biloop_classify)
+        for (int s0 = 0; s0 < nslots; s0 += 2) {
+          const int half = lane >> 5, l5 = lane & 31;
+          const int slot = s0 + half;
+          const int ra_ = slot, rb_ = slot == 0 ? -1 : m + 1 - slot;
+          const int na = slot < nslots ? m - ra_ + 1 : 0, nb = (slot < nslots && rb_ > ra_) ? m - rb_ + 1 : 0;
+          const bool in_a = l5 < na, in_b = !in_a && l5 < na + nb;
+          const int u1 = in_a ? ra_ : rb_, t5 = in_a ? l5 : l5 - na;
+          const int u2 = (m - u1) - t5;
+          const bool in = (in_a || in_b) && !(u1 == 0 && u2 == 0);
+          const int pp = in ? i + 1 + u1 : i + 1, q = in ? j - 1 - u2 : j - 1;
+          const int type2raw = ra_bp(lds, s[pp], s[q]);
+          const double as = EM(a_stem, pp - 1, q);
+          const double z = ra_loop_energy_bf(lds, c.big, type, ra_rtype(type2raw), in ? u1 : 0, in ? u2 : 0, bi1, bj1, s[pp - 1], s[q + 1]);
+          const double e = bs + z + as;
+          const bool ok = in && type2raw != 0 && as != kNegInf;
+          const bool nz = ok && e > -708.39641853226408; // ra_expd(e) != 0
+          const bool big = ok && e >= 89.0;
+          const unsigned long long nzall = __ballot(nz);
+          if (nzall == 0) continue;
+          const unsigned long long bigall = __ballot(big);
+#pragma unroll
+          for (int h = 0; h < 2; h++) { // (wave-uniform: scalar instructions)
+            const int sl = s0 + h;
+            if (sl >= nslots) continue;
+            const int a_ = sl, b_ = sl == 0 ? -1 : m + 1 - sl;
+            const int n_a = m - a_ + 1, n_b = b_ > a_ ? m - b_ + 1 : 0;
+            const unsigned hn = (unsigned)(nzall >> (32 * h)), hb = (unsigned)(bigall >> (32 * h));
+            const unsigned an = hn & ((n_a >= 32 ? 0u : (1u << n_a)) - 1u), ab = hb & ((n_a >= 32 ? 0u : (1u << n_a)) - 1u);
+            col_nz |= (unsigned long long)an << a_;
+            col_big |= (unsigned long long)ab << a_;
+            row_nz |= (an != 0 ? 1u : 0u) << a_;
+            row_big |= (ab != 0 ? 1u : 0u) << a_;
+            if (n_b > 0) {
+              const unsigned bn = (hn >> n_a) & ((1u << n_b) - 1u), bb = (hb >> n_a) & ((1u << n_b) - 1u);
+              col_nz |= (unsigned long long)bn << b_;
+              col_big |= (unsigned long long)bb << b_;
+              row_nz |= (bn != 0 ? 1u : 0u) << b_;
+              row_big |= (bb != 0 ? 1u : 0u) << b_;
+            }
+          }
+        }
+        if (row_nz == 0) continue;
+        // this lane's position: left ranges [i + 1, i + 1 + u1 - delta], right ranges [q + 1, j - delta]
+        const int qbase = j - 1 - m;
+        unsigned add = 0;
+        if (k >= i + 1) {
+          const int ustar = k - (i + 1 - delta); // the row whose left range ends at k
+          if (ustar >= 0 && ustar <= m) {
+            if ((row_nz >> ustar) & 1) add |= 2u | (((row_big >> ustar) & 1) ? 1u : 0u);
+          }
+          if (ustar < m) { // rows above: k lies inside their left ranges
+            const int sh = ustar < 0 ? 0 : ustar + 1;
+            if (row_nz >> sh) add |= 8u | ((row_big >> sh) ? 4u : 0u);
+          }
+        }
+        if (k <= kr1) { // right ranges: the tuples with q <= k - 1
+          const int nl = k - qbase;
+          if (nl > 0) {
+            const unsigned long long below = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+            if (col_nz & below) add |= (k == kr1 ? 2u : 8u) | ((col_big & below) ? (k == kr1 ? 1u : 4u) : 0u);
+          }
+        }
+        fl |= add;
+      }
+    }
+  }
+  const bool bbig = fl & 1, bnz = fl & 2, cbig = fl & 4, cnz = fl & 8;
+  const bool undecided = k <= L && !((cbig || !cnz) && (cbig || bbig || !bnz));
+  if (__ballot(undecided) != 0) return false;
+  if (k <= L) {
+    v.v(V_BP)[k - 1] = bnz ? __builtin_huge_val() : 0.0;
+    v.v(V_CBP)[k - 1] = cnz ? __builtin_huge_val() : 0.0;
+  }
+  return true;
+}
+
+// The bulge / interior-loop sums by windows of 64 positions, a wavefront each.  RaBatch::windows_all: every sequence (a launch
+// with few sequences: k_biloop is not launched at all); else only the sequences in the LOGSUM regime.
+__global__ __launch_bounds__(kBlock) void k_biloop_win(RaBatch b, RaConst c) {
+  __shared__ RaLds lds;
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.y;
+  const SeqView v = make_view(b, idx);
+  const int L = v.L;
+  const double pf = v.v(V_AO)[L];
+  const bool linear = pf >= -690 && pf <= 690; // raccess.cpp:500-507
+  // (both tests are the same for every thread of the workgroup: nobody is left waiting at the barrier of the table load)
+  if (linear && !b.windows_all) return; // the linear branch of this launch: k_biloop
+  if (1 + kWave * (int)(blockIdx.x * kWavesPerBlock) > L) return;
+  ra_load_lds(lds, c);
+  const int k0 = 1 + kWave * (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (k0 > L) return;
+  if (!linear) {
+    biloop_window<true>(lds, c, v, b.delta, lane, k0);
+  } else if (pf < 120.0 || !biloop_classify_window(lds, c, v, b.delta, lane, k0)) {
+    biloop_window<false>(lds, c, v, b.delta, lane, k0);
   }
 }
 
@@ -1389,12 +1515,12 @@ __device__ __forceinline__ double multi_prob(const RaLds &lds, const SeqView &v,
   return flag ? ra_expd(lds, temp - v.v(V_AO)[L]) : 0.0;
 }
 
+// (a thread per window start: blockIdx.y = the sequence, blockIdx.x = its chunk of kBlock positions)
 __global__ __launch_bounds__(kBlock) void k_access(RaBatch b, RaConst c) {
   __shared__ RaLds lds;
+  const int idx = blockIdx.y;
+  if (1 + (int)(blockIdx.x * kBlock) > b.desc[idx].L) return; // (the whole workgroup: before the barrier of the table load)
   ra_load_lds(lds, c);
-  const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (idx >= b.nseq) return;
   using SL = RaSmallLayout;
   const SeqView v = make_view(b, idx);
   const int L = v.L, W = v.W, S = v.S, delta = b.delta;
@@ -1407,7 +1533,7 @@ __global__ __launch_bounds__(kBlock) void k_access(RaBatch b, RaConst c) {
   const bool logsum = !(Z >= -690 && Z <= 690);
   float *acc = b.acc + v.out_off, *cond = b.cond + v.out_off;
 
-  for (int x = 1 + lane; x <= L; x += kWave) {
+  for (int x = 1 + (int)(blockIdx.x * kBlock + threadIdx.x); x <= L; x += L) { // (one position per thread)
     float acc_x = 0.0f;
     const bool has_acc = x + delta - 1 <= L;
     if (has_acc) {
@@ -1509,17 +1635,17 @@ hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int
       hipLaunchKernelGGL((k_inside<2, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
       hipLaunchKernelGGL((k_outside<2, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
     }
-    hipLaunchKernelGGL(k_biloop<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    if (!(b.windows_all && b.logsum_windows > 0)) hipLaunchKernelGGL(k_biloop<2>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
   } else {
     hipLaunchKernelGGL((k_inside<4, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
     hipLaunchKernelGGL((k_outside<4, 0>), dim3(blocks), dim3(kBlock), 0, stream, b, c);
-    hipLaunchKernelGGL(k_biloop<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+    if (!(b.windows_all && b.logsum_windows > 0)) hipLaunchKernelGGL(k_biloop<4>, dim3(blocks), dim3(kBlock), 0, stream, b, c);
   }
   if (b.logsum_windows > 0) {
     const int wblocks = (b.logsum_windows + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(k_biloop_logsum, dim3(wblocks, b.nseq), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_biloop_win, dim3(wblocks, b.nseq), dim3(kBlock), 0, stream, b, c);
   }
-  hipLaunchKernelGGL(k_access, dim3(blocks), dim3(kBlock), 0, stream, b, c);
+  hipLaunchKernelGGL(k_access, dim3((b.lmax + kBlock - 1) / kBlock, b.nseq), dim3(kBlock), 0, stream, b, c);
   return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@ constexpr int kRaMaxSpan = 255; // cells of a column / positions of a window: at
 struct RaBatch {
   const RaSeqDesc *desc;
   int32_t nseq;
+  int32_t lmax; // the longest sequence of the batch (grids over positions)
   int32_t W, delta;
   double *band;
   double *vec;
@@ -34,6 +35,9 @@ struct RaBatch {
   // > 0: the LOGSUM branch of the bulge / interior-loop sums is computed by k_biloop_logsum, a wavefront per window of
   // 64 positions, this many windows per sequence (>= the longest sequence's); 0: by the ordered pass on the sequence's own wavefront
   int32_t logsum_windows = 0;
+  // with logsum_windows > 0: the windows take the linear branch of every sequence as well (its classification pass and,
+  // where that cannot decide, the ordered sums) - a launch with few sequences, where a sequence's own wavefront is the bottleneck
+  int32_t windows_all = 0;
   // helper wavefronts per sequence for the big folds of the inside / outside passes (0, 1 or 2): a workgroup per sequence
   // instead of a wavefront - for the few sequences of a query batch, whose time is the latency of one wavefront's chain
   int32_t helpers = 0;

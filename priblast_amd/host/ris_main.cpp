@@ -27,6 +27,7 @@
 #include <chrono>
 #include <numeric>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <cctype>
 #include <cstdint>
@@ -639,12 +640,27 @@ int ris_main(int argc, char **argv) {
   } else {
     // round t: batch t * world + rank; every rank takes part in every round's gather, with or without a batch
     size_t t_next = 0;
-    auto gather_round = [&](size_t t, Prepared *p, std::vector<prb_hitset *> &pages) {
+    // The gathers run on a thread of their own, in round order, behind the search of the next batch (prb_gather_hits works
+    // on the communicator's own stream): rank 0, which receives everybody's records and copies them to the host, then takes no
+    // longer over a round than the others.  At most two rounds wait for it (their records stay in HBM until then).
+    struct GatherJob {
+      size_t t = 0;
+      bool has = false;
+      std::vector<int32_t> qlen;
+      std::vector<prb_hitset *> pages;
+    };
+    std::mutex gmu;
+    std::condition_variable gcv;
+    std::deque<GatherJob> gq;
+    bool gclosed = false;
+    auto gather_round_now = [&](GatherJob &gj) {
       BatchJob job;
-      job.index = t;
+      job.index = gj.t;
+      const size_t t = gj.t;
+      std::vector<prb_hitset *> &pages = gj.pages;
       for (int page = 0; page < npages; page++) {
         prb_hitset *mine = pages.empty() ? nullptr : pages[(size_t)page], *all = nullptr;
-        if (prb_gather_hits(comm, mine, p ? (int32_t)p->qlen_unmasked.size() : 0, p ? p->qlen_unmasked.data() : nullptr, 0, &all))
+        if (prb_gather_hits(comm, mine, gj.has ? (int32_t)gj.qlen.size() : 0, gj.has ? gj.qlen.data() : nullptr, 0, &all))
           die(std::string("Error: ") + prb_last_error());
         if (mine) prb_hitset_free(mine);
         if (all) job.pages.push_back(all);
@@ -663,6 +679,32 @@ int ris_main(int argc, char **argv) {
       job.qlen_unmasked.assign(ql, ql + job.nq);
       submit(t, std::move(job));
     };
+    std::thread gatherer([&] {
+      for (;;) {
+        GatherJob gj;
+        {
+          std::unique_lock<std::mutex> lk(gmu);
+          gcv.wait(lk, [&] { return !gq.empty() || gclosed; });
+          if (gq.empty()) return;
+          gj = std::move(gq.front());
+          gq.pop_front();
+        }
+        gcv.notify_all();
+        gather_round_now(gj);
+      }
+    });
+    auto gather_round = [&](size_t t, Prepared *p, std::vector<prb_hitset *> &pages) {
+      GatherJob gj;
+      gj.t = t;
+      gj.has = p != nullptr;
+      if (p) gj.qlen = p->qlen_unmasked;
+      gj.pages = pages;
+      std::unique_lock<std::mutex> lk(gmu);
+      gcv.wait(lk, [&] { return gq.size() < 2; });
+      gq.push_back(std::move(gj));
+      lk.unlock();
+      gcv.notify_all();
+    };
     work(workers[0],
          [&](size_t &b) {
            b = t_next * (size_t)world + (size_t)rank;
@@ -674,6 +716,12 @@ int ris_main(int argc, char **argv) {
     const size_t mine_rounds = nb > (size_t)rank ? (nb - (size_t)rank + (size_t)world - 1) / (size_t)world : 0;
     std::vector<prb_hitset *> none;
     for (size_t t = mine_rounds; t < njobs; t++) gather_round(t, nullptr, none);
+    {
+      std::lock_guard<std::mutex> lk(gmu);
+      gclosed = true;
+    }
+    gcv.notify_all();
+    gatherer.join();
   }
   writer.join();
   if (a.binary) {

@@ -98,7 +98,7 @@ def test_lengths_around_the_overflow_classification(ctx, oracle):
 
 def test_logsum_windows_match_the_ordered_pass(ctx, oracle, monkeypatch):
     """The LOGSUM branch of the bulge / interior-loop sums (|log Z| > 690) is computed by a wavefront per window of 64
-    positions (k_biloop_logsum); PRB_RACCESS_LOGSUM_WINDOWS=0 keeps the ordered pass on the sequence's own wavefront.
+    positions (k_biloop_win); PRB_RACCESS_LOGSUM_WINDOWS=0 keeps the ordered pass on the sequence's own wavefront.
     Both bit-identical to the oracle: GC-rich sequences (in the branch from ~1,200 nt), lengths around window edges, a
     sequence that is not in the branch in the same batch."""
     rng = np.random.default_rng(23)
@@ -135,3 +135,24 @@ def test_helper_wavefronts_do_not_change_a_bit(ctx, oracle, monkeypatch, helpers
             assert np.array_equal(bits(acc), bits(oa)), (helpers, W, len(s))
             assert np.array_equal(bits(cond), bits(oc)), (helpers, W, len(s))
     monkeypatch.delenv("PRB_RACCESS_HELPERS", raising=False)
+
+
+@pytest.mark.parametrize("windows_all", ["0", "1"])
+def test_bulge_interior_sums_by_windows(ctx, oracle, monkeypatch, windows_all):
+    """PRB_RACCESS_WINDOWS_ALL: the linear branch of the bulge / interior-loop sums per window of 64 positions too (its
+    classification and, where that cannot decide, the ordered sums; the default for launches of up to 512 sequences) or
+    on the sequence's own wavefront - lengths on both sides of log Z = 120, of the overflow classification and of 690,
+    windows that end at a sequence end, poly-A flanks (positions without any term) - bit-identical to the oracle."""
+    monkeypatch.setenv("PRB_RACCESS_WINDOWS_ALL", windows_all)
+    rng = np.random.default_rng(41)
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for n in (7, 63, 64, 65, 129, 380, 470, 600, 1000)]
+    seqs.append("".join(rng.choice(list("ACGU"), 900, p=[0.4, 0.1, 0.1, 0.4])))
+    seqs.append("".join(rng.choice(list("ACGU"), 500, p=[0.15, 0.35, 0.35, 0.15])))
+    seqs.append("A" * 300 + "".join(rng.choice(list("ACGU"), 400)) + "U" * 300)
+    seqs.append("".join(rng.choice(list("GGGCCCAU"), 1500)))
+    res = ctx.accessibility(seqs, 70, 5)
+    for s, (acc, cond) in zip(seqs, res):
+        oa, oc = oracle.raccess(s, 70, 5)
+        assert np.array_equal(bits(acc), bits(oa)), (windows_all, len(s))
+        assert np.array_equal(bits(cond), bits(oc)), (windows_all, len(s))
+    monkeypatch.delenv("PRB_RACCESS_WINDOWS_ALL", raising=False)
