@@ -56,7 +56,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GAPPED_BYTES_PER_HIT = 600.0   # 2 directions x (60 codes + 2 x 60 floats)
-STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped_front", "gapped_front_hits", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait", "host_search_range", "host_cands", "host_drain_tail", "host_download")
+STAGES = ("raccess", "seed", "ungapped", "sort", "filter", "gapped_front", "gapped_front_hits", "gapped_tier0_hits", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "traceback", "traceback_slow", "host_dfs", "host_dfs_wait", "host_search_range", "host_cands", "host_drain_tail", "host_download")
 SEED_BYTES_PER_HIT = 136.0     # SA entry + start_pos probe + code window + ~25 accessibility floats per seed hit
 RACCESS_BYTES_PER_NT = 8100.0  # 7 band tables x 72 x 8 B written once + read ~once
 RACCESS_LSE_PER_NT = 12400.0   # logsumexp per nucleotide (W = 70)
@@ -494,7 +494,8 @@ def main():
         front_done = ctx.stage_ms("gapped_front_hits")[1]
         gap_ms, gap_launch = stage["gapped"]
         rl_front = kernel_roofline("k_gapped_front", counts[1], front_ms, front_launch, GAPPED_BYTES_PER_HIT)
-        rl_tier0 = kernel_roofline("k_gapped_lds<0, Tier0, Rec32, true>", counts[1] - front_done, gap_ms, gap_launch, GAPPED_BYTES_PER_HIT)
+        tier0_in = ctx.stage_ms("gapped_tier0_hits")[1]  # hits that entered tier 0 (first pass: what the front kernel hands on; second: what it hands on again)
+        rl_tier0 = kernel_roofline("k_gapped_lds<0, Tier0, Rec32, true>", tier0_in, gap_ms, gap_launch, GAPPED_BYTES_PER_HIT)
         gapped_all_ms = sum(stage[s][0] for s in ("gapped_front", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow"))
         ung_ms, ung_launch = stage["ungapped"]
         ra_ms, ra_launch = stage["raccess"]
@@ -522,6 +523,7 @@ def main():
             "stage_ms_per_step": {s: round(stage[s][0] / a.steps, 3) for s in STAGES},
             "slow_path_hits_per_step": ctx.stage_ms("slow_hits")[1] // a.steps,
             "front_kernel_hits_per_step": ctx.stage_ms("gapped_front_hits")[1] // a.steps,
+            "tier0_hits_per_step": ctx.stage_ms("gapped_tier0_hits")[1] // a.steps,
             "host_wall_ms_per_step": {k: round(v / a.steps * 1e3, 1) for k, v in wall.items()},
             "roofline": rl_front if front_ms >= gap_ms else rl_tier0,
             "stage_roofline": {

@@ -90,7 +90,7 @@ int prb_ctx_synchronize(prb_ctx *ctx);
  * reset, and launch counts: "raccess", "seed" (keys + sort of the candidates' pairs or rows - what of it is not issued
  * ahead, beside the sub-batch before), "ungapped" (one-pass form: k_seed_extend, seeds found and extended), "sort",
  * "filter", "gapped_front" (the kernel in front of the gapped cascade: the hits whose two directions find nothing;
- * "gapped_front_hits": launches = hits it completed), "gapped" (LDS tier 0),
+ * "gapped_front_hits": launches = hits it completed), "gapped" (LDS tier 0; "gapped_tier0_hits": launches = hits that entered it),
  * "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow" (wavefront-per-hit kernel), "traceback", "traceback_slow";
  * host wall-clock pseudo stages: "host_dfs" (background seed DFS), "host_dfs_wait",
  * "host_search_range", "host_cands", "host_drain_tail", "host_download" (the synchronous copy of

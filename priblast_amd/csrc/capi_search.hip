@@ -1501,6 +1501,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
           if ((rc = run_wave(0, cur, m, bufs[nb], nullptr, handover))) return rc;
           m = 0;
         } else {
+          if (tier == 0) ctx->timers["gapped_tier0_hits"].launches += m; // (a counter, not a time: hits that entered tier 0)
           PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                     firstc, w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
                                     w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,

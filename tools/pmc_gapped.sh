@@ -14,8 +14,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_A
   timeout -k 10 280 rocprofv3 --kernel-trace --pmc $set --kernel-include-regex 'k_gapped_front|k_gapped_lds<0.*Tier0' --output-format csv -d $OUT/$tag -- python3 $R/bench.py $ARGS > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }
   echo "done $tag"
 done
-read ALL FRONT <<< $(python3 -c "
-import json;d=json.load(open('$OUT/plain.json'));print(d['config']['hits_per_step']['ungapped'], d['front_kernel_hits_per_step'])")
-python3 $R/tools/pmc_to_json.py $OUT 'k_gapped_front' $ALL 'k_gapped_front' $R/profiles/r03_pmc_gapped_front.json "bench.py $ARGS under rocprofv3 --kernel-trace --pmc, one pass per counter set (tools/pmc_gapped.sh); units = every post-ungapped hit of the step"
-python3 $R/tools/pmc_to_json.py $OUT 'k_gapped_lds<0.*Tier0' $((ALL - FRONT)) 'k_gapped_lds<0, Tier0, Rec32, true>' $R/profiles/r03_pmc_gapped_tier0.json "bench.py $ARGS under rocprofv3 --kernel-trace --pmc, one pass per counter set (tools/pmc_gapped.sh); units = the hits the front kernel hands on"
+read ALL T0 <<< $(python3 -c "
+import json;d=json.load(open('$OUT/plain.json'));print(d['config']['hits_per_step']['ungapped'], d['tier0_hits_per_step'])")
+python3 $R/tools/pmc_to_json.py $OUT 'k_gapped_front' $ALL 'k_gapped_front' $R/profiles/r03_pmc_gapped_front.json "bench.py $ARGS under rocprofv3 --kernel-trace --pmc, one pass per counter set (tools/pmc_gapped.sh); units = every post-ungapped hit of the step (the kernel's second launch per query, on the second directions of what the tiers stopped behind, is in the counters and the time)"
+python3 $R/tools/pmc_to_json.py $OUT 'k_gapped_lds<0.*Tier0' $T0 'k_gapped_lds<0, Tier0, Rec32, true>' $R/profiles/r03_pmc_gapped_tier0.json "bench.py $ARGS under rocprofv3 --kernel-trace --pmc, one pass per counter set (tools/pmc_gapped.sh); units = the hits that enter tier 0: what the front kernel hands on (first directions), then what it hands on again (second directions)"
 cp $R/profiles/r03_pmc_gapped_*.json $R/gpurun_out/
