@@ -28,15 +28,21 @@ int DevBuf::ensure(size_t bytes) {
     cap = 0;
     if (e != hipSuccess) return hip_fail(e, "hipFree");
   }
-  size_t want = bytes + bytes / 8;
+  // (room to grow into, except for the giants: an eighth of 64 GB is what the next buffer lacks)
+  size_t want = bytes > ((size_t)8 << 30) ? bytes : bytes + bytes / 8;
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
+    (void)hipGetLastError(); // (the failed attempt is not the next launch's error)
     e = hipMalloc(&p, bytes);
     want = bytes;
   }
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     p = nullptr;
-    set_error("out of device memory allocating " + std::to_string(bytes) + " bytes");
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    set_error("out of device memory allocating " + std::to_string(bytes) + " bytes (" + std::to_string(free_b >> 20) + " MiB of " +
+              std::to_string(total_b >> 20) + " free)");
     return PRB_ERR_NOMEM;
   }
   cap = want;
@@ -307,13 +313,21 @@ int run_accessibility(prb_ctx *ctx, int32_t nseq, const char *seqs, const int64_
       // helper wavefronts for the big folds when the launch leaves most of the GPU idle anyway (three workgroups of three
       // wavefronts fit a compute unit); PRB_RACCESS_HELPERS = 0 / 1 / 2 says otherwise
       const char *h = std::getenv("PRB_RACCESS_HELPERS");
-      b.helpers = h ? std::max(0, std::min(2, std::atoi(h))) : (n <= 512 ? 2 : 0);
+      b.helpers = h ? std::max(0, std::min(3, std::atoi(h))) : (n <= 512 ? 3 : 0);
       const char *wa = std::getenv("PRB_RACCESS_WINDOWS_ALL"); // (tests: 0 / 1 whatever the size of the launch)
       b.windows_all = wa ? (std::atoi(wa) != 0) : (n <= 512);
     }
     if ((rc = ctx->time_begin())) return rc;
     PRB_HIP(ra_launch(b, ctx->ra_const, band, vec, ctx->stream));
     if ((rc = ctx->time_end("raccess", 1))) return rc; // synchronises: host staging vectors may be reused
+    if (b.helpers == 3) {
+      int tripped = 0;
+      PRB_HIP(ra_watchdog_tripped(&tripped, ctx->stream));
+      if (tripped) {
+        set_error("Raccess: a wavefront gave up waiting for its workgroup (PRB_RACCESS_HELPERS=2 avoids that form of the passes)");
+        return PRB_ERR_STATE;
+      }
+    }
     pos = end;
   }
   return PRB_OK;

@@ -101,6 +101,18 @@ struct SearchWs {
     return PRB_OK;
   }
   PinnedBuf pinned, cand_pinned[2], tb_pinned, pin_hits[2], pin_bp[2];
+  bool trim_next = false; // the last sub-batch had a giant list: its buffers are let go before the next one starts
+  // every stage buffer over 256 MB (not the front stage's, which may hold the next sub-batch already, nor the packed results,
+  // which may still be on their way to the host)
+  void trim() {
+    for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
+                      &sortTmp, &endKey, &pmax, &state, &keep, &surv, &first, &gapScratch, &overflow, &subset, &subset2, &cidx, &ntrace,
+                      &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin,
+                      &row_cand, &seed_qacc, &resumePool, &resumePool2, &resumePool3, &frontScratch, &listC, &keptU, &keptFirst, &keptTier,
+                      &keptNtrace, &keptTrace})
+      if (b->cap > ((size_t)256 << 20)) b->release();
+    trim_next = false;
+  }
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
@@ -837,6 +849,7 @@ static int sort_hits(prb_ctx *ctx, SearchWs &w, const HitRec *recs, HitSoA out, 
     }
   }
   // the general form works on the fields as arrays
+  if (getenv("PRB_DEBUG_MEM")) fprintf(stderr, "[mem] sort: the general form (%lld hits)\n", (long long)n);
   if ((rc = w.hitsTmp.ensure(hits_bytes(n)))) return rc;
   const HitSoA in = carve_hits(w.hitsTmp, n);
   PRB_HIP(launch_gather_recs_to_hits(recs, nullptr, in, n, ctx->stream));
@@ -938,12 +951,27 @@ static int filter_hits(prb_ctx *ctx, SearchWs &w, const HitSoA &h, int64_t n, do
 // follows; idxbuf[i] = index in `in`.
 // `have` records already in recbuf are kept (the new ones are appended behind them).
 // Room for `more` records behind the `have` records that `recbuf` holds (which are kept).
+// PRB_DEBUG_MEM: free device memory at the stations of a search
+static void mem_note(const char *where, const SearchWs &w) {
+  static const bool on = getenv("PRB_DEBUG_MEM") != nullptr;
+  if (!on) return;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  fprintf(stderr, "[mem] %-18s free %7zu MiB | hitsA %6zu hitsB %6zu hitsC %6zu hitsTmp %6zu MiB\n", where, free_b >> 20, w.hitsA.cap >> 20,
+          w.hitsB.cap >> 20, w.hitsC.cap >> 20, w.hitsTmp.cap >> 20);
+}
+
 static int reserve_recs(prb_ctx *ctx, DevBuf &recbuf, int64_t have, int64_t more) {
   int rc;
   const size_t need = ((size_t)have + (size_t)more) * sizeof(HitRec);
   if (have > 0 && need > recbuf.cap) { // grow and keep what is there
     DevBuf bigger;
-    if ((rc = bigger.ensure(need + need / 2))) return rc;
+    // (with room to spare while memory allows: every growth is a copy of everything; a list of 1e9 records - 64 GB - must
+    // still be able to grow next to its old copy)
+    // (past 16 GB only a sixth: what is spare here is missing in the sort behind)
+    if ((rc = need > ((size_t)16 << 30) ? PRB_ERR_NOMEM : bigger.ensure(need + need / 2)) && (rc = bigger.ensure(need + need / 6)) &&
+        (rc = bigger.ensure(need)))
+      return rc;
     PRB_HIP(hipMemcpyAsync(bigger.p, recbuf.p, (size_t)have * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
     recbuf.release();
@@ -958,7 +986,7 @@ static int grow_keep(prb_ctx *ctx, DevBuf &buf, size_t have, size_t need) {
   int rc;
   if (have > 0 && need > buf.cap) {
     DevBuf bigger;
-    if ((rc = bigger.ensure(need + need / 2))) return rc;
+    if ((rc = bigger.ensure(need + need / 2)) && (rc = bigger.ensure(need + need / 6)) && (rc = bigger.ensure(need))) return rc;
     PRB_HIP(hipMemcpyAsync(bigger.p, buf.p, have, hipMemcpyDeviceToDevice, ctx->stream));
     PRB_HIP(hipStreamSynchronize(ctx->stream));
     buf.release();
@@ -1102,6 +1130,10 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   const int delta = db->hdr.min_accessible_length;
   ExtOpts eo{delta, opts.drop_out_wo_gap, opts.drop_out_w_gap, opts.min_helix_length};
   int rc;
+  if (w.trim_next) {
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    w.trim();
+  }
   // ---- seeds: one row per (candidate, db SA entry) ----
   if (ncand64 == 0) return PRB_OK;
   if (ncand64 > INT32_MAX) {
@@ -1292,6 +1324,23 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if (last_stage == 1) return PRB_OK;
   // ---- sort, redundancy filter ----
   if (m1 == 0) return PRB_OK;
+  // A list this long (one very long query against a large page: 1.2e9 hits pass -f for 45 kb against 100 M characters) needs
+  // the memory that buffers of stages already over still hold: the seed pools now, the sort keys and the records behind the
+  // sort.  (hipFree waits for the device: only where it is needed.)
+  const bool big_list = hits_bytes(m1) > ((size_t)20 << 30);
+  mem_note("seed chunks done", w);
+  if (big_list) {
+    w.trim_next = true;
+    PRB_HIP(hipStreamSynchronize(ctx->stream));
+    w.front.release();
+    for (DevBuf *b : {&w.hitsA, &w.hitsTmp, &w.row_count, &w.row_off, &w.row_cand, &w.seed_qacc, &w.cands, &w.trace, &w.resumePool,
+                      &w.resumePool2, &w.resumePool3, &w.keptU, &w.keptTrace})
+      b->release();
+    // (and this context's Raccess workspace, up to 48 GB when it last took a large batch: its launches are over)
+    for (DevBuf *b : {&ctx->ra_band, &ctx->ra_vec, &ctx->ra_codes, &ctx->ra_desc}) b->release();
+    if ((rc = w.front.init())) return rc;
+  }
+  mem_note("before the sort", w);
   if ((rc = w.hitsC.ensure(hits_bytes(m1)))) return rc;
   HitSoA B = carve_hits(w.hitsC, m1);
   uint32_t *perm = nullptr;
@@ -1300,6 +1349,11 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   if (all_one_pass && one_pass_maxlen > 0 && !getenv("PRB_SORT_TWO_LENGTHS")) sb1.eq_len_max = (int32_t)one_pass_maxlen;
   if ((rc = sort_hits(ctx, w, w.hitsB.as<HitRec>(), B, m1, qb->nq, sb1, &perm))) return rc;
   if ((rc = ctx->time_end("sort", 9))) return rc;
+  if (big_list) { // (the records and the sort's keys are dead)
+    perm = nullptr;
+    for (DevBuf *b : {&w.hitsB, &w.kE, &w.kL, &w.kQ, &w.kP, &w.kTmp, &w.kTmp2, &w.idxA, &w.idxB, &w.sortTmp}) b->release();
+  }
+  mem_note("sorted", w);
   int64_t nung = 0;
   if ((rc = ctx->time_begin())) return rc;
   if ((rc = filter_hits(ctx, w, B, m1, opts.interaction_threshold, &nung))) return rc;

@@ -159,6 +159,35 @@ __device__ __forceinline__ double cell_value_desc(const double (&reg)[NP], int d
   return lane_value_asc<NP>(reg, dmax - d);
 }
 
+// ---- kH = 3 (see k_inside): the wavefronts of a sequence's workgroup hand batches of terms to each other through LDS
+// counters instead of workgroup barriers, so that the sequence's own wavefront is free to run its chains meanwhile.
+// All wavefronts of a workgroup are resident together, so waiting on one another cannot deadlock; a wait that does not
+// end (a bug) trips a watchdog: the wavefront raises the workgroup's abort flag and g_ra_watchdog and ENDS - a barrier
+// does not wait for ended wavefronts -, the others follow at their next wait, the host reports PRB_ERR_STATE.
+__device__ int g_ra_watchdog;
+struct FoldSync {
+  int prod[2]; // batches helper 1 / helper 2 have written (running count over the whole sequence)
+  int cons;    // batches the folding wavefront has taken
+  int abort;
+};
+// false: give up (the caller returns from the kernel)
+__device__ __forceinline__ bool fold_wait(FoldSync &fs, int &counter, int target) {
+  for (int n = 0;; n++) {
+    if (__hip_atomic_load(&counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+    if (__hip_atomic_load(&fs.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || n > (1 << 21)) {
+      __hip_atomic_store(&fs.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      g_ra_watchdog = 1;
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void fold_post(int &counter, int value, int lane) {
+  // (the LDS operations of a wavefront complete in order: the batch written by all its lanes is there before the count)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -175,12 +204,21 @@ __global__ void k_fill(double *p, int64_t n, double value) {
 // wavefront runs it and so knows without a word how many rounds there are), evaluate the terms of the NEXT batch of eight -
 // fetch, loop energies - into LDS while the owner folds the batch before; a workgroup barrier per batch.  The fold order
 // is untouched.  For the few sequences of a query batch, whose time is the latency of one wavefront's chain.
+// kH = 3: two helpers and a FOLDING wavefront; the sequence's own wavefront keeps phases 1 - 3 and the last step of phase 4.
+// The big fold of column j needs nothing of phases 2 and 3 until its very end (Alpha_multi, one term), and they need nothing
+// of it: phase 1, a barrier, then the fold (helpers -> folding wavefront, LDS counters) BESIDE phases 2 + 3, a barrier, the
+// last term.  A column costs phase 1 + the longer of the two instead of their sum.
 template <int NP, int kH>
 __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_inside(RaBatch b, RaConst c) {
+  constexpr bool kF = kH == 3;
   __shared__ RaLds lds;
   __shared__ RowMasks rowmasks[kH ? 1 : kWavesPerBlock];
   __shared__ double xbuf[kH ? 2 : 1][kHB][kH ? kWave : 1]; // kH > 0: the terms of two batches, [batch & 1][term][lane]
   __shared__ int xflag[2];                                       // ... and whether there is a batch after them
+  __shared__ FoldSync fsync;
+  __shared__ double fold_out[kF ? NP : 1][kF ? kWave : 1]; // kF: the folds of a column's cells, [pass][lane]
+  if (kF && threadIdx.x == 0) fsync.prod[0] = fsync.prod[1] = fsync.cons = fsync.abort = 0;
+  int seq = 0; // kF: batches so far (the same count in the helpers and the folding wavefront)
   ra_load_lds(lds, c);
   const int lane = threadIdx.x & 63;
   const int role = kH ? (int)(threadIdx.x >> 6) : 0; // 0: the sequence's own wavefront
@@ -207,13 +245,13 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
     // lane mapping: d = dtop - lane, dtop = dmax, dmax-64, ...  (the last pass holds the
     // small spans, which are the cheap ones in every inside phase)
     const int dmax = imin(j, W + 1);
+    double to_reg[NP], mb_reg[NP];
     if (role == 0) { // ---- phases 1 - 3: the sequence's own wavefront ----
     if (lane == 0) rowmask_clear(rm, j - 2); // the row that gets its first cell in column j + 1
 
     // phase 1: Alpha_stem (raccess.cpp:102-129) and Alpha_multi2 (:145-162): both need only
     // column j-1 and the cell itself.  Also, per cell, the term it contributes to Alpha_outer[j] (:230-241),
     // kept in a register for the chain of phase 3.
-    double to_reg[NP], mb_reg[NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) to_reg[k] = mb_reg[k] = kNegInf;
     int pass = 0;
@@ -261,9 +299,12 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
     }
     wave_sync();
     RA_PROF(1);
+    } // role == 0
+    if constexpr (kF) __syncthreads(); // phase 1 (Alpha_stem, the row masks) before the helpers read them
 
+    if (role == 0) {
     // phase 2: Alpha_multibif (:131-143) then Alpha_multi1 (:164-175)
-    pass = 0;
+    int pass = 0;
     for (int dtop = dmax; dtop >= kTurn; dtop -= kWave, pass++) {
       const int d = dtop - lane;
       const bool cell = d >= kTurn;
@@ -334,7 +375,101 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
     // reference's order - p ascending, q ascending - by the lane that owns the cell; a lane walks only the
     // terms that exist (set bits of the rows of Alpha_stem, spans max(5, d - 30) .. d - u1), eight at a time:
     // their band entries and sequence codes are fetched together, then folded one by one.
-    if constexpr (kH > 0) {
+    if constexpr (kF) {
+      if (role != 0 && j != L) {
+        const int bj = s[j];
+        int pass = 0;
+        for (int dtop = dmax; dtop >= kTurn; dtop -= kWave, pass++) {
+          const int d = dtop - lane;
+          const bool cell = d >= kTurn;
+          const int i = cell ? j - d : 0;
+          const int type = cell ? ra_bp(lds, s[i], s[j + 1]) : 0;
+          const int bi1 = cell ? s[i + 1] : 0;
+          double temp = type != 0 ? ra_hairpin_energy(lds, type, d, bi1, bj) : 0.0;
+          const int m = type != 0 ? imin(kMaxLoop, d - (kTurn + 2)) : -1;
+          const int span_lo = imax(kTurn + 2, d - kMaxLoop);
+          int u1 = -1;
+          uint32_t wbits = 0;
+          bool more = m >= 0;
+          bool pend = __ballot(more) != 0; // (the same in every wavefront: from the cells themselves)
+          while (pend) {
+            const int buf = seq & 1;
+            if (role == 3) { // the fold
+              if (!fold_wait(fsync, fsync.prod[0], seq + 1) || !fold_wait(fsync, fsync.prod[1], seq + 1)) return;
+#pragma unroll
+              for (int t = 0; t < kHB; t++) {
+                const double x = xbuf[buf][t][lane];
+                const double rr = ra_lse(lds, temp, x);
+                temp = x != kNegInf ? rr : temp;
+              }
+              pend = xflag[buf] != 0;
+              fold_post(fsync.cons, seq + 1, lane);
+            } else { // a helper: which terms (both, identically), the values of its half of the batch
+              if (!fold_wait(fsync, fsync.cons, seq - 1)) return; // (the batch that was in this buffer is folded)
+              int su1[kHB], sspan[kHB];
+#pragma unroll
+              for (int t = 0; t < kHB; t++) {
+                const bool adv = more && wbits == 0 && u1 < m;
+                u1 += adv ? 1 : 0;
+                const uint32_t wnew = rowmask_window(rm, i + (u1 < 0 ? 0 : u1), span_lo, d - u1 - (u1 == 0 ? 1 : 0));
+                wbits = adv ? wnew : wbits;
+                const bool has = more && wbits != 0;
+                sspan[t] = span_lo + __builtin_ctz(wbits | 0x80000000u);
+                su1[t] = has ? u1 : -1;
+                wbits = has ? (wbits & (wbits - 1)) : wbits;
+                more = more && (wbits != 0 || u1 < m);
+              }
+              const int t0 = role == 1 ? 0 : kHB / 2;
+              double sts[kHB / 2];
+              int su2[kHB / 2], sq[kHB / 2], sq1[kHB / 2], sp0[kHB / 2], sp1[kHB / 2];
+#pragma unroll
+              for (int t = 0; t < kHB / 2; t++) {
+                const int u = su1[t0 + t];
+                const bool ok = u >= 0;
+                const int p = ok ? i + u : i, q = ok ? p + sspan[t0 + t] : j;
+                su2[t] = j - q;
+                sts[t] = EM(a_stem, p, q);
+                sq[t] = s[q];
+                sq1[t] = s[q + 1];
+                sp0[t] = s[p];
+                sp1[t] = s[p + 1];
+              }
+#pragma unroll
+              for (int t = 0; t < kHB / 2; t++) {
+                const int u = su1[t0 + t];
+                const int type2 = ra_rtype(ra_bp(lds, sp1[t], sq[t]));
+                const double z = ra_loop_energy_bf(lds, c.big, type, type2, u < 0 ? 0 : u, su2[t], bi1, bj, sp0[t], sq1[t]);
+                xbuf[buf][t0 + t][lane] = (u >= 0 && sts[t] != kNegInf && type2 != 0) ? sts[t] + z : kNegInf;
+              }
+              pend = __ballot(more) != 0;
+              if (role == 1 && lane == 0) xflag[buf] = pend ? 1 : 0;
+              fold_post(fsync.prod[role - 1], seq + 1, lane);
+            }
+            seq++;
+          }
+          if (role == 3) fold_out[pass][lane] = temp;
+        }
+      }
+      __syncthreads(); // the folds, and phases 2 - 3 (Alpha_multi) beside them
+      if (role == 0 && j != L) { // the last term of phase 4
+        const int bj = s[j];
+        int pass = 0;
+        for (int dtop = dmax; dtop >= kTurn; dtop -= kWave, pass++) {
+          const int d = dtop - lane;
+          if (d < kTurn) continue;
+          const int i = j - d;
+          const int type = ra_bp(lds, s[i], s[j + 1]);
+          double out = kNegInf;
+          if (type != 0) {
+            const int tt = ra_rtype(type);
+            out = ra_lse(lds, fold_out[pass][lane],
+                         EM(a_multi, i, j) + MLclosing + MLintern + lds.small[SL::kDangle3 + tt * 5 + s[i + 1]] +
+                             lds.small[SL::kDangle5 + tt * 5 + bj]);
+          }
+          EM(a_stemend, i, j) = out;
+        }
+      }
+    } else if constexpr (kH > 0) {
       __syncthreads(); // the owner's phases 1 - 3 (Alpha_stem, the row masks) before the helpers read them
       if (j != L) {
         const int bj = s[j];
@@ -577,12 +712,19 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
 
 // ----------------------------------------------------------------------------- outside
 // (kH: helper wavefronts for the big fold, see k_inside)
+// kH = 3: phase A, a barrier, then the big fold of phase E (helpers -> folding wavefront) beside phases B - D on the
+// sequence's own wavefront, a barrier, the last two terms of phase E (they need Beta_multi2 of phase D) - see k_inside.
 template <int NP, int kH>
 __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_outside(RaBatch b, RaConst c) {
+  constexpr bool kF = kH == 3;
   __shared__ RaLds lds;
   __shared__ RowMasks rowmasks[kH ? 1 : kWavesPerBlock];
   __shared__ double xbuf[kH ? 2 : 1][kHB][kH ? kWave : 1];
   __shared__ int xflag[2];
+  __shared__ FoldSync fsync;
+  __shared__ double fold_out[kF ? NP : 1][kF ? kWave : 1];
+  if (kF && threadIdx.x == 0) fsync.prod[0] = fsync.prod[1] = fsync.cons = fsync.abort = 0;
+  int seq = 0;
   ra_load_lds(lds, c);
   const int lane = threadIdx.x & 63;
   const int role = kH ? (int)(threadIdx.x >> 6) : 0;
@@ -625,16 +767,16 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
     // lane mapping: d = dbot + lane, dbot = 3, 67, ... (the last pass holds the large
     // spans, which are the cheap ones in every outside phase)
     const int dmax = imin(q, W + 1);
+    double xb_reg[NP], tob_reg[NP];
+    const int pend_o = imin(q + W, L); // Beta_outer[q - 1] sums p' = q .. pend_o
 
     if (role == 0) { // ---- phases A - D: the sequence's own wavefront ----
     // phase A: Beta_stemend (:278-279), copy from column q+1
     if (use_masks && lane == 0) rowmask_clear(rm, q - W); // the row whose first cell comes in column q - 1 (spans >= W never exist)
     // Also, in registers for the chains of phase B: per cell the term it contributes to Beta_multi (:296-300), and
     // - one per lane, p' = q + lane (+ 64) - the terms of Beta_outer[q - 1] (:262-269).
-    double xb_reg[NP], tob_reg[NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) xb_reg[k] = tob_reg[k] = kNegInf;
-    const int pend_o = imin(q + W, L); // Beta_outer[q - 1] sums p' = q .. pend_o
     {
       int pass = 0;
       for (int dbot = kTurn; dbot <= dmax; dbot += kWave, pass++) {
@@ -667,7 +809,10 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
     }
     wave_sync();
     RA_PROF(8);
+    } // role == 0
+    if constexpr (kF) __syncthreads(); // phase A (Beta_stemend, the row masks) before the helpers read them
 
+    if (role == 0) {
     // phase B, two serial chains in one instruction stream (see k_inside's phase 3): Beta_multi (:281-308), p
     // ascending (d descending), on lane 0; Beta_outer[q - 1] (:260-271), p' ascending, on lane 1; inputs by v_readlane.
     {
@@ -782,6 +927,114 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
     }
 
     } // role == 0
+    if constexpr (kF) {
+      if (role != 0) {
+        int pass = 0;
+        for (int dbot = kTurn; dbot <= dmax; dbot += kWave, pass++) {
+          const int d = dbot + lane;
+          const bool cell = d <= dmax;
+          const int p = cell ? q - d : 1;
+          const int t2raw = cell ? ra_bp(lds, s[p + 1], s[q]) : 0;
+          const int type2 = ra_rtype(t2raw);
+          const int bp0 = cell ? s[p] : 0, bq1 = cell ? s[q + 1] : 0;
+          double temp = 0;
+          if (role == 3 && t2raw != 0) temp = ao[p] + bo[q] + dangle_energy(lds, v, t2raw, p, q);
+          int u1 = t2raw != 0 ? imin(imin(kMaxLoop, p - 1), W + 1 - d) + 1 : 0; // (one above the first row)
+          uint32_t wbits = 0;
+          int span0 = 0;
+          bool more = t2raw != 0 && u1 > 0;
+          bool pend = __ballot(more) != 0;
+          while (pend) {
+            const int buf = seq & 1;
+            if (role == 3) { // the fold
+              if (!fold_wait(fsync, fsync.prod[0], seq + 1) || !fold_wait(fsync, fsync.prod[1], seq + 1)) return;
+#pragma unroll
+              for (int t = 0; t < kHB; t++) {
+                const double x = xbuf[buf][t][lane];
+                const double rr = ra_lse(lds, temp, x);
+                temp = x != kNegInf ? rr : temp;
+              }
+              pend = xflag[buf] != 0;
+              fold_post(fsync.cons, seq + 1, lane);
+            } else {
+              if (!fold_wait(fsync, fsync.cons, seq - 1)) return;
+              int su1[kHB], sspan[kHB];
+#pragma unroll
+              for (int t = 0; t < kHB; t++) {
+                const bool adv = more && wbits == 0 && u1 > 0;
+                u1 -= adv ? 1 : 0;
+                const int u2max = imin(imin(kMaxLoop - u1, L - 1 - q), W + 1 - d - u1);
+                const int s0 = d + u1 + (u1 == 0 ? 1 : 0); // (i, j) == (p, q) is excluded (:377)
+                const uint32_t wnew = rowmask_window(rm, p - u1, s0, d + u1 + u2max);
+                wbits = adv ? wnew : wbits;
+                span0 = adv ? s0 : span0;
+                const bool has = more && wbits != 0;
+                sspan[t] = span0 + __builtin_ctz(wbits | 0x80000000u);
+                su1[t] = has ? u1 : -1;
+                wbits = has ? (wbits & (wbits - 1)) : wbits;
+                more = more && (wbits != 0 || u1 > 0);
+              }
+              const int t0 = role == 1 ? 0 : kHB / 2;
+              double ses[kHB / 2];
+              int su2[kHB / 2], sj[kHB / 2], sj1[kHB / 2], si0[kHB / 2], si1[kHB / 2];
+#pragma unroll
+              for (int t = 0; t < kHB / 2; t++) {
+                const int u = su1[t0 + t];
+                const bool ok = u >= 0;
+                const int i = ok ? p - u : p, j = ok ? i + sspan[t0 + t] : q; // (a lane without a term reads its own cell)
+                su2[t] = j - q;
+                ses[t] = EM(b_stemend, i, j);
+                sj[t] = s[j];
+                sj1[t] = s[j + 1];
+                si0[t] = s[i];
+                si1[t] = s[i + 1];
+              }
+#pragma unroll
+              for (int t = 0; t < kHB / 2; t++) {
+                const int u = su1[t0 + t];
+                const int type = ra_bp(lds, si0[t], sj1[t]);
+                const double z = ra_loop_energy_bf(lds, c.big, type, type2, u < 0 ? 0 : u, su2[t], si1[t], sj[t], bp0, bq1);
+                xbuf[buf][t0 + t][lane] = (u >= 0 && ses[t] != kNegInf && type != 0) ? ses[t] + z : kNegInf;
+              }
+              pend = __ballot(more) != 0;
+              if (role == 1 && lane == 0) xflag[buf] = pend ? 1 : 0;
+              fold_post(fsync.prod[role - 1], seq + 1, lane);
+            }
+            seq++;
+          }
+          if (role == 3) fold_out[pass][lane] = temp;
+        }
+      }
+      __syncthreads(); // the folds, and phases B - D (Beta_multi2) beside them
+      if (role == 0) { // the last terms of phase E
+        int pass = 0;
+        for (int dbot = kTurn; dbot <= dmax; dbot += kWave, pass++) {
+          const int d = dbot + lane;
+          if (d > dmax) continue;
+          const int p = q - d;
+          const int t2raw = ra_bp(lds, s[p + 1], s[q]);
+          double out = kNegInf;
+          if (t2raw != 0) {
+            const int type2 = ra_rtype(t2raw);
+            double temp = fold_out[pass][lane];
+            if (p != 0 && q != L) {
+              const int type = ra_bp(lds, s[p], s[q + 1]);
+              if (type != 0 && d + 2 <= W + 1) {
+                const double ps = EM(b_stem, p - 1, q + 1);
+                if (ps != kNegInf) temp = ra_lse(lds, temp, ps + lds.small[SL::kStack + type * 7 + type2]);
+              }
+            }
+            out = temp;
+            const double m2 = EM(b_multi2, p, q);
+            if (m2 != kNegInf) {
+              const double x = m2 + MLintern + dangle_energy(lds, v, t2raw, p, q);
+              out = ra_lse(lds, x, out);
+            }
+          }
+          EM(b_stem, p, q) = out;
+        }
+      }
+    } else {
     if constexpr (kH > 0) __syncthreads(); // the owner's phases A - D (Beta_stemend, the row masks) before the helpers read them
 
     // phase E: Beta_stem (:367-409).  Enclosing pairs (i = p - u1, j+1 = q + u2 + 1) in the reference's
@@ -986,6 +1239,7 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
         if (role == 0) EM(b_stem, p, q) = out;
       }
     }
+    } // !kF
     wave_sync();
     RA_PROF(12);
   }
@@ -1611,6 +1865,21 @@ extern "C" int prb_debug_ra_profile(unsigned long long *out, int reset) {
 }
 #endif
 
+// whether a wait between the wavefronts of a workgroup (kH = 3) has given up since the last call; clears the flag.
+// (After the launch has completed.)
+hipError_t ra_watchdog_tripped(int *tripped, hipStream_t stream) {
+  *tripped = 0;
+  hipError_t e = hipMemcpyFromSymbolAsync(tripped, HIP_SYMBOL(g_ra_watchdog), sizeof(int), 0, hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (*tripped) {
+    const int zero = 0;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ra_watchdog), &zero, sizeof(int), 0, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  return e;
+}
+
 hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int64_t vec_elems,
                      hipStream_t stream) {
   if (b.nseq <= 0) return hipSuccess;
@@ -1625,7 +1894,10 @@ hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int
     // wavefront's chain, the GPU otherwise idle.  Many (a database): a wavefront per sequence, as many side by side as fit.
     const int helpers = b.helpers >= 0 ? b.helpers : 0;
     const bool masks = b.W + 2 + kMaxLoop <= 128;
-    if (helpers == 2 && masks) {
+    if (helpers == 3 && masks) {
+      hipLaunchKernelGGL((k_inside<2, 3>), dim3(b.nseq), dim3(kWave * 4), 0, stream, b, c);
+      hipLaunchKernelGGL((k_outside<2, 3>), dim3(b.nseq), dim3(kWave * 4), 0, stream, b, c);
+    } else if (helpers == 2 && masks) {
       hipLaunchKernelGGL((k_inside<2, 2>), dim3(b.nseq), dim3(kWave * 3), 0, stream, b, c);
       hipLaunchKernelGGL((k_outside<2, 2>), dim3(b.nseq), dim3(kWave * 3), 0, stream, b, c);
     } else if (helpers == 1 && masks) {

@@ -38,7 +38,8 @@ struct RaBatch {
   // with logsum_windows > 0: the windows take the linear branch of every sequence as well (its classification pass and,
   // where that cannot decide, the ordered sums) - a launch with few sequences, where a sequence's own wavefront is the bottleneck
   int32_t windows_all = 0;
-  // helper wavefronts per sequence for the big folds of the inside / outside passes (0, 1 or 2): a workgroup per sequence
+  // helper wavefronts per sequence for the big folds of the inside / outside passes (0, 1, 2; 3 = two helpers and a wavefront
+  // that folds, beside the sequence's own, which keeps the other phases): a workgroup per sequence
   // instead of a wavefront - for the few sequences of a query batch, whose time is the latency of one wavefront's chain
   int32_t helpers = 0;
 };
@@ -46,6 +47,8 @@ struct RaBatch {
 // Enqueue fill + inside + outside + biloop + accessibility for a batch on `stream`.
 hipError_t ra_launch(const RaBatch &b, const RaConst &c, int64_t band_elems, int64_t vec_elems,
                      hipStream_t stream);
+
+hipError_t ra_watchdog_tripped(int *tripped, hipStream_t stream);
 
 // doubles / bytes needed for a sequence of length L
 inline int64_t ra_band_elems(int L, int W) { return (int64_t)kRaBands * (L + 2) * (W + 2); }

@@ -119,10 +119,11 @@ def test_logsum_windows_match_the_ordered_pass(ctx, oracle, monkeypatch):
     monkeypatch.delenv("PRB_RACCESS_LOGSUM_WINDOWS", raising=False)
 
 
-@pytest.mark.parametrize("helpers", ["0", "1", "2"])
+@pytest.mark.parametrize("helpers", ["0", "1", "2", "3"])
 def test_helper_wavefronts_do_not_change_a_bit(ctx, oracle, monkeypatch, helpers):
-    """PRB_RACCESS_HELPERS: the big folds of the inside / outside passes with 0, 1 or 2 helper wavefronts per sequence
-    (a workgroup per sequence; the default for batches of up to 512 sequences is 2) - ragged batch, both passes over the
+    """PRB_RACCESS_HELPERS: the big folds of the inside / outside passes with 0, 1 or 2 helper wavefronts per sequence, or
+    (3, the default for batches of up to 512 sequences) two helpers and a wavefront that folds beside the sequence's own,
+    which runs the other phases meanwhile (a workgroup per sequence) - ragged batch, both passes over the
     cells of a column (W = 70: 69 cells), a span that leaves the row masks (W = 100: helpers do not apply) - bit-identical
     to the oracle."""
     monkeypatch.setenv("PRB_RACCESS_HELPERS", helpers)
