@@ -987,6 +987,134 @@ __global__ __launch_bounds__(kBlock) void k_filter_final(HitSoA h, int64_t n, co
   keep[i] = k;
 }
 
+// The same two scans on a WINDOW of the list held in LDS.  A scan is a chain of dependent loads - the running maximum,
+// the box, the state of the hit before, and so on, ~4 hits back and ~4 forward - and as loads from L2 that chain is what
+// the kernels above cost (0.96 / 1.5 ms per 23 M hits where the list itself is 0.1 ms of HBM traffic).  A workgroup
+// loads the boxes of its 256 hits and of the neighbours on both sides once, coalesced, and scans in LDS; a scan that
+// leaves the window goes on in memory.  k_filter_round_tile also repeats its round within the window until nothing
+// changes (a state only ever goes from unknown to final, so more rounds, in any interleaving, give the same result):
+// what is left for the next launch are the chains that cross a window.
+constexpr int kFilterBack = 128, kFilterFwd = 128, kFilterWin = kFilterBack + kBlock + kFilterFwd;
+struct FilterWindow {
+  int qs[kFilterWin], qe[kFilterWin], ds[kFilterWin], de[kFilterWin], query[kFilterWin];
+  double e[kFilterWin];
+  int64_t pmax[kFilterWin];
+  uint8_t state[kFilterWin];
+  int64_t w0, w1; // the hits [w0, w1) of the list
+};
+__device__ __forceinline__ void window_load(FilterWindow &w, const HitSoA &h, int64_t n, const int64_t *__restrict__ pmax,
+                                            const uint8_t *state, int64_t t0, int fwd) {
+  const int64_t w0 = t0 > kFilterBack ? t0 - kFilterBack : 0;
+  const int64_t w1 = t0 + kBlock + fwd < n ? t0 + kBlock + fwd : n;
+  if (threadIdx.x == 0) {
+    w.w0 = w0;
+    w.w1 = w1;
+  }
+  for (int64_t g = w0 + threadIdx.x; g < w1; g += kBlock) {
+    const int k = (int)(g - w0);
+    const int qs = h.q_sp[g], ds = h.db_sp[g];
+    w.qs[k] = qs;
+    w.ds[k] = ds;
+    w.qe[k] = qs + US(h.q_len[g]) - 1;
+    w.de[k] = ds + US(h.db_len[g]) - 1;
+    w.query[k] = h.query[g];
+    w.e[k] = h.e_tot[g];
+    w.pmax[k] = pmax[g];
+    w.state[k] = state[g];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ Box window_box(const FilterWindow &w, const HitSoA &h, int64_t g) {
+  if (g >= w.w0 && g < w.w1) {
+    const int k = (int)(g - w.w0);
+    return Box{w.qs[k], w.qe[k], w.ds[k], w.de[k], w.query[k], w.e[k]};
+  }
+  return box_of(h, g);
+}
+__device__ __forceinline__ int64_t window_pmax(const FilterWindow &w, const int64_t *__restrict__ pmax, int64_t g) {
+  return g >= w.w0 && g < w.w1 ? w.pmax[g - w.w0] : pmax[g];
+}
+__device__ __forceinline__ uint8_t window_state(const FilterWindow &w, const uint8_t *state, int64_t g) {
+  return g >= w.w0 && g < w.w1 ? ((const volatile uint8_t *)w.state)[g - w.w0] : ((const volatile uint8_t *)state)[g];
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter_round_tile(HitSoA h, int64_t n, const int64_t *__restrict__ pmax, uint8_t *state,
+                                                              int32_t *pending) {
+  __shared__ FilterWindow w;
+  __shared__ int s_progress;
+  const int64_t t0 = (int64_t)blockIdx.x * kBlock, i = t0 + threadIdx.x;
+  window_load(w, h, n, pmax, state, t0, 0);
+  bool mine = i < n && window_state(w, state, i) == kUnknown;
+  const Box b = i < n ? window_box(w, h, i) : Box{0, 0, 0, 0, 0, 0.0};
+  const int64_t need = pack_end(b.query, b.de);
+  for (int iter = 0; iter < 64; iter++) {
+    if (threadIdx.x == 0) s_progress = 0;
+    __syncthreads();
+    if (mine) {
+      bool wait = false;
+      uint8_t res = kActive;
+      for (int64_t a = i - 1; a >= 0; a--) {
+        if (window_pmax(w, pmax, a) < need) break; // nothing at or before a (in this query) reaches b's db end
+        const Box c = window_box(w, h, a);
+        if (c.query != b.query) break;
+        if (contains(c, b) && c.e <= b.e) {
+          const uint8_t sa = window_state(w, state, a);
+          if (sa == kActive) {
+            res = kInactive;
+            wait = false;
+            break;
+          }
+          if (sa == kUnknown) wait = true;
+        }
+      }
+      if (!wait) {
+        ((volatile uint8_t *)w.state)[i - w.w0] = res;
+        state[i] = res;
+        mine = false;
+        s_progress = 1;
+      }
+    }
+    __syncthreads();
+    const int p = s_progress;
+    __syncthreads();
+    if (!p) break;
+  }
+  if (mine) *pending = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter_final_tile(HitSoA h, int64_t n, const int64_t *__restrict__ pmax,
+                                                              const uint8_t *__restrict__ state, uint8_t *keep) {
+  __shared__ FilterWindow w;
+  const int64_t t0 = (int64_t)blockIdx.x * kBlock, i = t0 + threadIdx.x;
+  window_load(w, h, n, pmax, state, t0, kFilterFwd);
+  if (i >= n) return;
+  uint8_t k = 0;
+  if (window_state(w, state, i) == kActive) {
+    k = 1;
+    const Box a = window_box(w, h, i);
+    for (int64_t j = i + 1; j < n && k; j++) {
+      const Box b = window_box(w, h, j);
+      if (b.query != a.query || b.ds > a.de) break;
+      if (contains(a, b) && a.e > b.e) {
+        // was b already flagged when a's scan reached it?  (by an active hit before a)
+        const int64_t need = pack_end(b.query, b.de);
+        bool flagged = false;
+        for (int64_t c = i - 1; c >= 0; c--) {
+          if (window_pmax(w, pmax, c) < need) break;
+          const Box x = window_box(w, h, c);
+          if (x.query != b.query) break;
+          if (window_state(w, state, c) == kActive && contains(x, b) && x.e <= b.e) {
+            flagged = true;
+            break;
+          }
+        }
+        if (!flagged) k = 0;
+      }
+    }
+  }
+  keep[i] = k;
+}
+
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 } // namespace
@@ -1198,13 +1326,17 @@ hipError_t launch_filter_init(const HitSoA &h, int64_t n, double thr, int64_t *e
 hipError_t launch_filter_round(const HitSoA &h, int64_t n, const int64_t *pmax, uint8_t *state, int32_t *pending,
                                hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_filter_round, grid_for(n), dim3(kBlock), 0, s, h, n, pmax, state, pending);
+  const bool tiles = !(getenv("PRB_FILTER_TILES") && atoi(getenv("PRB_FILTER_TILES")) == 0);
+  if (tiles) hipLaunchKernelGGL(k_filter_round_tile, grid_for(n), dim3(kBlock), 0, s, h, n, pmax, state, pending);
+  else hipLaunchKernelGGL(k_filter_round, grid_for(n), dim3(kBlock), 0, s, h, n, pmax, state, pending);
   return hipGetLastError();
 }
 hipError_t launch_filter_final(const HitSoA &h, int64_t n, const int64_t *pmax, const uint8_t *state, uint8_t *keep,
                                hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_filter_final, grid_for(n), dim3(kBlock), 0, s, h, n, pmax, state, keep);
+  const bool tiles = !(getenv("PRB_FILTER_TILES") && atoi(getenv("PRB_FILTER_TILES")) == 0);
+  if (tiles) hipLaunchKernelGGL(k_filter_final_tile, grid_for(n), dim3(kBlock), 0, s, h, n, pmax, state, keep);
+  else hipLaunchKernelGGL(k_filter_final, grid_for(n), dim3(kBlock), 0, s, h, n, pmax, state, keep);
   return hipGetLastError();
 }
 } // namespace prb
