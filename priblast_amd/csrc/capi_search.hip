@@ -48,7 +48,7 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, listC, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, listC, slowList, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
   // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
   // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
   // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
@@ -108,7 +108,7 @@ struct SearchWs {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &surv, &first, &gapScratch, &overflow, &subset, &subset2, &cidx, &ntrace,
                       &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin,
-                      &row_cand, &seed_qacc, &resumePool, &resumePool2, &resumePool3, &frontScratch, &listC, &keptU, &keptFirst, &keptTier,
+                      &row_cand, &seed_qacc, &resumePool, &resumePool2, &resumePool3, &frontScratch, &listC, &slowList, &keptU, &keptFirst, &keptTier,
                       &keptNtrace, &keptTrace})
       if (b->cap > ((size_t)256 << 20)) b->release();
     trim_next = false;
@@ -116,7 +116,7 @@ struct SearchWs {
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &listC, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &listC, &slowList, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
       b->release();
     front.release();
     if (copy_stream) {
@@ -1540,10 +1540,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     // the LDS tiers and the wavefront-per-hit kernel on the list (cur, m), each taking what the one before it could not hold
     const char *skip_env = getenv("PRB_GAPPED_SKIP_TIERS"); // experiment: bit t set = LDS tier t is left out behind the front kernel
     int skip_mask = 0;
-    auto run_cascade = [&](int handover) -> int {
+    // (hold_wave: the list is handed back before the wavefront-per-hit kernel instead - see run_slow)
+    auto run_cascade = [&](int handover, bool hold_wave) -> int {
       for (size_t c = 0; c < cascade.size() && m > 0; c++) {
         const int tier = cascade[c];
         if (tier < kLdsTiers - 1 && ((skip_mask >> tier) & 1)) continue;
+        if (tier == kWaveTier && hold_wave) break;
         if (tier == kWaveTier && front_free && !front_called && !handover) { // (see below: the longest extensions run nearly alone)
           front_free();
           front_called = true;
@@ -1582,7 +1584,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       skip_mask = skip_env ? atoi(skip_env) : 0;
     }
     if (!handover) {
-      if ((rc = run_cascade(0))) return rc;
+      if ((rc = run_cascade(0, false))) return rc;
     } else if (m > 0) {
       // The hits that are left have a direction that finds something - or had too many cells for the front kernel.  Nine
       // SECOND directions in ten still find nothing, and a tier pays for proving that what it pays for 16 anti-diagonals of
@@ -1593,8 +1595,16 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       const int64_t m1 = m;
       if ((rc = w.listC.ensure((size_t)m1 * 4))) return rc;
       PRB_HIP(hipMemcpyAsync(w.listC.p, cur, (size_t)m1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      if ((rc = run_cascade(1))) return rc;
-      // the hits an LDS tier or the wavefront-per-hit kernel stopped behind their first direction
+      if ((rc = run_cascade(1, true))) return rc;
+      // What outgrew the last LDS tier - ~150 extensions per configs[2] query, a wavefront each for 2 ms on a GPU that is
+      // otherwise idle - waits for the second pass's: ONE launch of the wavefront-per-hit kernel for both (a launch lasts
+      // as long as its longest extension; these hits run both their directions there).
+      int64_t n_slow = m;
+      if (n_slow > 0) {
+        if ((rc = w.slowList.ensure((size_t)n_slow * 4))) return rc;
+        PRB_HIP(hipMemcpyAsync(w.slowList.p, cur, (size_t)n_slow * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      // the hits an LDS tier stopped behind their first direction
       PRB_HIP(launch_flag_marked(w.tierOf.as<uint8_t>(), w.listC.as<uint32_t>(), m1, kHandoverMark, w.overflow.as<uint8_t>(), ctx->stream));
       cur = w.listC.as<uint32_t>();
       m = m1;
@@ -1609,7 +1619,25 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
           PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 4 * 3, ctx->stream));
         }
         if ((rc = run_front())) return rc;
-        if ((rc = run_cascade(0))) return rc;
+        if ((rc = run_cascade(0, true))) return rc;
+      }
+      if (n_slow + m > 0) {
+        if (m > 0) { // both passes' lists as one
+          if ((rc = grow_keep(ctx, w.slowList, (size_t)n_slow * 4, (size_t)(n_slow + m) * 4))) return rc;
+          PRB_HIP(hipMemcpyAsync(w.slowList.as<uint32_t>() + n_slow, cur, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        cur = w.slowList.as<uint32_t>();
+        m += n_slow;
+        if (front_free && !front_called) {
+          front_free();
+          front_called = true;
+        }
+        if ((rc = ctx->time_begin())) return rc;
+        hs->slow_hits += m;
+        ctx->slow_hits += m;
+        if ((rc = run_wave(0, cur, m, bufs[nb], nullptr, 0))) return rc;
+        m = 0;
+        if ((rc = ctx->time_end(kTierTimer[kWaveTier], 1))) return rc;
       }
     }
   }
