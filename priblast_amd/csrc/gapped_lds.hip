@@ -82,8 +82,14 @@ struct Tier0 { // 1,280 B per hit: 4 workgroups of 256 threads (32 hits) are exa
   static constexpr bool kResumes = false;
   static constexpr bool kPairSteps = true; // two anti-diagonals per step where that is safe (dir_step_pair)
 };
+#ifndef PRB_T1_CAPD // (geometry experiments: tools/tier_geometry.sh)
+#define PRB_T1_CAPD 40
+#define PRB_T1_CAPR 64
+#define PRB_T1_GROUPS 32
+#define PRB_T1_WGCU 3
+#endif
 struct Tier1 { // 1.65 KB per hit, 3 workgroups of 256 threads (32 hits) per CU: the hits a little too long for tier 0
-  static constexpr int kG = 8, kCapD = 40, kCapR = 64, kGroups = 32, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr int kG = 8, kCapD = PRB_T1_CAPD, kCapR = PRB_T1_CAPR, kGroups = PRB_T1_GROUPS, kWavesPerSimd = 3, kWgPerCu = PRB_T1_WGCU;
   static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 0, leaves its own
   using From = Tier0;
   using FromRec = Rec32;
