@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
   enum { kLoad, kInit, kRun, kFinished, kDone };
   int phase = w < a.n ? kLoad : kDone, flag = 0;
   // (with two anti-diagonals per step a direction without improvement takes (drop + 1) / 2 steps)
-  const int period = kPair ? (a.o.drop_w_gap > 1 ? (a.o.drop_w_gap + 1) / 2 : 1) : (a.o.drop_w_gap > 1 ? a.o.drop_w_gap : 1);
+  const int period = a.period > 0 ? a.period : kPair ? (a.o.drop_w_gap > 1 ? (a.o.drop_w_gap + 1) / 2 : 1) : (a.o.drop_w_gap > 1 ? a.o.drop_w_gap : 1);
   int tick = 0; // iterations since the last boundary
   HitCtx c;
   DirState d;
@@ -1539,6 +1539,11 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
   GapArgs a{in,      out,   n,      subset, qb,        pg,         sc, o, overflow, tier_out, tier, first_flag, bp_count,
             trace,   bp_off, bp_out, next_work, rin,     rout};
   a.handover = mode == 0 ? handover : 0;
+  if (const char *pe = getenv("PRB_GAPPED_PERIOD")) { // experiment: "p0,p1,p2,p3" lockstep iterations between boundaries, per tier (0: default)
+    int p[4] = {0, 0, 0, 0};
+    sscanf(pe, "%d,%d,%d,%d", &p[0], &p[1], &p[2], &p[3]);
+    a.period = mode == 0 && tier >= 0 && tier < 4 ? p[tier] : 0;
+  }
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
   if (tier == 2) return launch_tier<Tier2, Rec32>(a, mode, s);

@@ -12,6 +12,6 @@ import json, sys
 r = json.loads(open(f"gpurun_out/sweep_{sys.argv[1]}.json").read().strip().splitlines()[-1])
 s = r["stage_ms_per_step"]
 print("[%s]" % sys.argv[2], "q/s %.3f" % r["value"], "ms/step %.0f" % r["ms_per_step"],
-      {k: round(s[k]) for k in ("seed", "ungapped", "sort", "filter", "gapped", "raccess")}, flush=True)
+      {k: round(s[k]) for k in ("ungapped", "sort", "filter", "gapped_front", "gapped", "gapped_t1", "gapped_t2", "gapped_t3", "gapped_slow", "raccess")}, flush=True)
 PY
 done
