@@ -1327,7 +1327,9 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // A list this long (one very long query against a large page: 1.2e9 hits pass -f for 45 kb against 100 M characters) needs
   // the memory that buffers of stages already over still hold: the seed pools now, the sort keys and the records behind the
   // sort.  (hipFree waits for the device: only where it is needed.)
-  const bool big_list = hits_bytes(m1) > ((size_t)20 << 30);
+  size_t big_bytes = (size_t)20 << 30;
+  if (const char *e = getenv("PRB_BIG_LIST_BYTES")) big_bytes = (size_t)atof(e); // (tests: every list takes this path)
+  const bool big_list = hits_bytes(m1) > big_bytes;
   mem_note("seed chunks done", w);
   if (big_list) {
     w.trim_next = true;

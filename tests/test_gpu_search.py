@@ -163,7 +163,8 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
                                  "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_HANDOVER=0", "PRB_GAPPED_HANDOVER=0,PRB_GAPPED_NO_RESUME", "PRB_GAPPED_RESUME_CAP", "PRB_GAPPED_CHUNK_HITS=37", "PRB_GAPPED_CHUNK_HITS=500,PRB_TRACE_SLOT_CAP=1", "PRB_GAPPED_FRONT=0", "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=1", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
-                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS", "PRB_FILTER_TILES=0"])
+                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS", "PRB_FILTER_TILES=0", "PRB_BIG_LIST_BYTES=1",
+                                 "PRB_BIG_LIST_BYTES=1,PRB_GAPPED_CHUNK_HITS=500,PRB_SEARCH_CHUNK_PAIRS=20000"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
     LDS kernel (normally only the extensions that outgrow the smaller tiers) must give the same
