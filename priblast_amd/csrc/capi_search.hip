@@ -48,7 +48,7 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, listC, slowList, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, listC, slowList, slowSlot, slowCnt, slowTrace, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
   // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
   // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
   // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
@@ -108,7 +108,7 @@ struct SearchWs {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &surv, &first, &gapScratch, &overflow, &subset, &subset2, &cidx, &ntrace,
                       &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin,
-                      &row_cand, &seed_qacc, &resumePool, &resumePool2, &resumePool3, &frontScratch, &listC, &slowList, &keptU, &keptFirst, &keptTier,
+                      &row_cand, &seed_qacc, &resumePool, &resumePool2, &resumePool3, &frontScratch, &listC, &slowList, &slowSlot, &slowCnt, &slowTrace, &keptU, &keptFirst, &keptTier,
                       &keptNtrace, &keptTrace})
       if (b->cap > ((size_t)256 << 20)) b->release();
     trim_next = false;
@@ -116,7 +116,7 @@ struct SearchWs {
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &listC, &slowList, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &listC, &slowList, &slowSlot, &slowCnt, &slowTrace, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
       b->release();
     front.release();
     if (copy_stream) {
@@ -1460,7 +1460,30 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // Wave-per-hit kernel with its state in HBM scratch, for the device list `cur` (indices into U;
   // nullptr = all) of m hits.  mode 0 writes G and retries hits that still overflow with a 4x
   // larger scratch; mode 2 writes base pairs at off_dev (indexed by list position).
+  // (long traces, search_kernels.hpp: not when the stage runs in chunks - the kept lists renumber the hits -, not for a
+  // list that is every hit - PRB_GAPPED_FIRST_TIER=4 -; PRB_TRACE_NO_LONG / PRB_TRACE_LONG_CAP are for the tests)
+  LongTrace lt;
+  int32_t lt_used = 0;
   auto run_wave = [&](int mode, const uint32_t *cur, int64_t m, uint32_t *spare, const int64_t *off_dev, int handover = 0) -> int {
+    if (mode == 0 && !chunked && cur == nullptr && m <= 65536 && !getenv("PRB_TRACE_NO_LONG")) { // (every hit, as a list)
+      if ((rc = w.slowList.ensure((size_t)m * 4))) return rc;
+      PRB_HIP(launch_iota_u32(w.slowList.as<uint32_t>(), m, ctx->stream));
+      cur = w.slowList.as<uint32_t>();
+    }
+    if (mode == 0 && !chunked && cur != nullptr && m <= 65536 && !getenv("PRB_TRACE_NO_LONG")) {
+      const char *ce = getenv("PRB_TRACE_LONG_CAP");
+      const int32_t cap = ce ? std::max(1, atoi(ce)) : 1024;
+      if (lt_used == 0) {
+        if ((rc = w.slowSlot.ensure((size_t)nmax * 4))) return rc;
+        PRB_HIP(hipMemsetAsync(w.slowSlot.p, 0xFF, (size_t)nmax * 4, ctx->stream));
+      }
+      const size_t have = (size_t)lt_used, need = have + (size_t)m;
+      if ((rc = grow_keep(ctx, w.slowCnt, have * 8, need * 8)) || (rc = grow_keep(ctx, w.slowTrace, have * 8 * cap, need * 8 * cap))) return rc;
+      PRB_HIP(hipMemsetAsync(w.slowCnt.as<int32_t>() + have * 2, 0xFF, (size_t)m * 8, ctx->stream));
+      PRB_HIP(launch_assign_slots(cur, m, lt_used, w.slowSlot.as<int32_t>(), ctx->stream));
+      lt_used += (int32_t)m;
+      lt = LongTrace{w.slowTrace.as<uint32_t>(), w.slowCnt.as<int32_t>(), w.slowSlot.as<int32_t>(), cap};
+    }
     int cap_diag = 512, cap_rec = 2048;
     if (mode != 0) { // caps known to suffice for every hit seen so far
       cap_diag = std::max(512, ctx->max_gap_caps);
@@ -1472,7 +1495,8 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
       if ((rc = scratch_for(m, cap_diag, cap_rec, gs))) return rc;
       PRB_HIP(launch_gapped_wave(U, G, m, cur, qb->view, pd, sc, eo, gs, mode, mode == 0 ? w.overflow.as<uint8_t>() : nullptr,
                                  mode == 0 ? w.tierOf.as<uint8_t>() : nullptr, firstc,
-                                 mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream, handover));
+                                 mode == 0 ? w.ntrace.as<int32_t>() : nullptr, off_dev, w.bpOut.as<int32_t>(), ctx->stream, handover,
+                                 mode == 0 ? lt : LongTrace{}));
       if (mode != 0) break;
       int64_t again = 0;
       if ((rc = select_overflow(cur, m, other, &again))) return rc;
@@ -1771,7 +1795,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     const int64_t total = off[nfin];
     if ((rc = w.bpOut.ensure((size_t)std::max<int64_t>(total, 1) * 8))) return rc;
     PRB_HIP(hipMemcpyAsync(w.bpOff.p, off, (size_t)(nfin + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, first_all, ntrace_all, tier_all, trace_all,
+    PRB_HIP(launch_bp_expand(U, nfin, w.subset.as<uint32_t>(), qb->view, pd, sc, first_all, ntrace_all, tier_all, trace_all, lt,
                              w.bpOff.as<int64_t>(), w.bpOut.as<int32_t>(), ctx->stream));
     std::vector<uint32_t> tlist[kWaveTier + 1];
     std::vector<int64_t> toff[kWaveTier + 1];
@@ -1780,6 +1804,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     const int slot_cap = cap_env ? std::min(kTraceCap, atoi(cap_env)) : kTraceCap;
     for (int64_t i = 0; i < nfin; i++) {
       const int t = std::min<int>(tier_fin[i] & 7, kWaveTier);
+      if (!no_slots && (tier_fin[i] & 7) == kLongTraceTier && lt.slot) continue; // (its chains are on record: launch_bp_expand wrote its pairs)
       if (no_slots || t == kWaveTier || (int)(ntr[i] & 0xFFFF) > slot_cap || (int)(ntr[i] >> 16) > slot_cap) {
         tlist[t].push_back(pre[i]);
         toff[t].push_back(off[i]);

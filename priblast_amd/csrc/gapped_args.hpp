@@ -70,6 +70,7 @@ struct GapArgs {
   // mode 0: state dumps of hits that outgrow an LDS tier, for the next one to continue from
   // (slot[x] = -1: none): `rin` = what this kernel may continue, `rout` = where it leaves its own
   GapResume rin, rout;
+  LongTrace lt;     // mode 0, the wavefront-per-hit kernel: where it leaves whole traceback chains (search_kernels.hpp)
   int period = 0;   // LDS tiers: lockstep iterations between the boundaries at which groups change direction / hit (0: the drop-out length)
   int handover = 0; // mode 0, LDS tiers and the wavefront-per-hit kernel: stop behind a first direction that this kernel ran (kHandoverMark)
 };

@@ -1197,12 +1197,19 @@ __device__ __forceinline__ void hit_dir_done(const GapArgs &a, HitCtx &c, int fl
   c.ovf = r.overflow;
   if (c.ovf) return;
   int cnt = 0;
+  int lslot = -1; // the wavefront-per-hit kernel: the hit's slot of the long traces
+  if constexpr (kMode == 0 && !kLds) lslot = a.lt.slot ? a.lt.slot[c.x] : -1;
   for (int k = r.best; k != 0; k = R::pred(S.info(k)), cnt++) {
     if (kMode == 0 && kLds && gl == 0 && cnt < kTraceCap) {
       const auto v = S.info(k);
       a.trace[(c.x * 2 + flag) * kTraceCap + cnt] = (uint16_t)(R::i(v) | (R::j(v) << 8));
     }
+    if (kMode == 0 && !kLds && gl == 0 && lslot >= 0 && cnt < a.lt.cap) {
+      const auto v = S.info(k);
+      a.lt.trace[((int64_t)lslot * 2 + flag) * a.lt.cap + cnt] = (uint32_t)R::i(v) | ((uint32_t)R::j(v) << 16);
+    }
   }
+  if (kMode == 0 && !kLds && gl == 0 && lslot >= 0) a.lt.count[lslot * 2 + flag] = cnt <= a.lt.cap ? cnt : -2;
   if (flag == 0) c.nleft = cnt;
   else c.nright = cnt;
   if (kMode == 2 && gl == 0) {
@@ -1250,7 +1257,15 @@ __device__ __forceinline__ void hit_store(const GapArgs &a, int64_t w, const Hit
     }
     if (!c.ovf) {
       const int64_t x = c.x;
-      a.tier_out[x] = (uint8_t)(a.tier_id > c.tier0 ? a.tier_id : c.tier0);
+      int tcode = a.tier_id > c.tier0 ? a.tier_id : c.tier0;
+      if (a.tier_id == kWaveTier && a.lt.slot) { // both chains on record?  (the first one possibly in an LDS tier's trace slot)
+        const int ls = a.lt.slot[x];
+        if (ls >= 0) {
+          const int c0 = a.lt.count[ls * 2], c1 = a.lt.count[ls * 2 + 1];
+          if ((c0 >= 0 || (c0 == -1 && c.nleft <= kTraceCap)) && c1 >= 0) tcode = kLongTraceTier;
+        }
+      }
+      a.tier_out[x] = (uint8_t)tcode;
       a.bp_count[x] = c.nleft | (c.nright << 16);
       // GappedExtension::Run tail (gapped_extension.cpp:49-67): dangling ends on both sides
       const double d0 = dangle_energy_gapped(sc, h.q_sp, h.db_sp, 0, qs, c.qn, ds, a.pg.nchars);
@@ -1553,11 +1568,12 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
-                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s, int handover) {
+                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s, int handover, const LongTrace &lt) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,    n,      subset,  qb,      pg,      sc,      o, overflow, tier_out, kWaveTier, first_flag, bp_count,
             nullptr, bp_off, bp_out, nullptr, GapResume{nullptr, nullptr, nullptr, 0}, GapResume{nullptr, nullptr, nullptr, 0}};
   a.handover = mode == 0 ? handover : 0;
+  if (mode == 0) a.lt = lt;
   const int blocks = scratch.nthreads; // here: number of wavefronts that own a state block
   if (scratch.base == nullptr) { // state in LDS
     const size_t lds = scratch.bytes_per_thread;
@@ -1570,19 +1586,34 @@ hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uin
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_assign_slots(const uint32_t *__restrict__ list, int64_t n, int32_t base, int32_t *slot) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) slot[list[p]] = base + (int32_t)p;
+}
+hipError_t launch_assign_slots(const uint32_t *list, int64_t n, int32_t base, int32_t *slot, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_assign_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, n, base, slot);
+  return hipGetLastError();
+}
+
 // Base pairs of final hit w from the trace slot its extension pass left (same layout as mode 2
 // of the gapped kernels writes).  Hits completed by the wave kernel (tier 3) or with a chain
 // longer than the slot are left to the mode-2 pass.
 __global__ __launch_bounds__(256) void k_bp_expand(HitSoA in, int64_t n, const uint32_t *__restrict__ subset, QBatchDev qb,
                                                    PageDev pg, SearchConst sc, const uint8_t *__restrict__ first_flag,
                                                    const int32_t *__restrict__ ntrace, const uint8_t *__restrict__ tier_of,
-                                                   const uint16_t *__restrict__ trace, const int64_t *__restrict__ bp_off,
+                                                   const uint16_t *__restrict__ trace, LongTrace lt, const int64_t *__restrict__ bp_off,
                                                    int32_t *bp_out) {
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (w >= n) return;
   const int64_t x = subset[w];
   const int nleft = ntrace[x] & 0xFFFF, nright = (int)((uint32_t)ntrace[x] >> 16);
-  if (tier_of[x] >= kWaveTier || nleft > kTraceCap || nright > kTraceCap) return;
+  // a hit of the wavefront-per-hit kernel with its chains on record (kLongTraceTier): the second direction from its long
+  // trace, the first one from there too unless an LDS tier ran it (then from that tier's trace slot)
+  const int ls = (tier_of[x] == kLongTraceTier && lt.slot) ? lt.slot[x] : -1;
+  if (ls < 0 && (tier_of[x] >= kWaveTier || nleft > kTraceCap || nright > kTraceCap)) return;
+  const uint32_t *lt_left = ls >= 0 && lt.count[ls * 2] >= 0 ? lt.trace + ((int64_t)ls * 2) * lt.cap : nullptr;
+  const uint32_t *lt_right = ls >= 0 ? lt.trace + ((int64_t)ls * 2 + 1) * lt.cap : nullptr;
   const int q_sp = in.q_sp[x], db_sp = in.db_sp[x], len = US(in.q_len[x]);
   const uint8_t *qs = qb.enc + qb.off[in.query[x]] + q_sp;
   const uint8_t *ds = pg.seqs + db_sp;
@@ -1598,26 +1629,27 @@ __global__ __launch_bounds__(256) void k_bp_expand(HitSoA in, int64_t n, const u
     }
   const uint16_t *sl = trace + x * 2 * kTraceCap;
   for (int t = 0; t < nleft; t++) {
-    const int v = sl[t];
+    const int ci = lt_left ? (int)(lt_left[t] & 0xFFFF) : (sl[t] & 0xFF), cj = lt_left ? (int)(lt_left[t] >> 16) : (sl[t] >> 8);
     const int64_t pos = unsorted ? out0 + ndiag + t : out0 + t;
-    bp_out[2 * pos] = q_sp - (v & 0xFF);
-    bp_out[2 * pos + 1] = db_sp - (v >> 8);
+    bp_out[2 * pos] = q_sp - ci;
+    bp_out[2 * pos + 1] = db_sp - cj;
   }
   const int q_end = q_sp + in.q_len[x] - 1, db_end = db_sp + in.db_len[x] - 1;
   for (int t = 0; t < nright; t++) {
-    const int v = sl[kTraceCap + t];
+    const int ci = lt_right ? (int)(lt_right[t] & 0xFFFF) : (sl[kTraceCap + t] & 0xFF),
+              cj = lt_right ? (int)(lt_right[t] >> 16) : (sl[kTraceCap + t] >> 8);
     const int64_t pos = unsorted ? out0 + ndiag + nleft + t : out0 + nleft + ndiag + (nright - 1 - t);
-    bp_out[2 * pos] = q_end + (v & 0xFF);
-    bp_out[2 * pos + 1] = db_end + (v >> 8);
+    bp_out[2 * pos] = q_end + ci;
+    bp_out[2 * pos + 1] = db_end + cj;
   }
 }
 
 hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                             const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
-                            const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
+                            const uint16_t *trace, const LongTrace &lt, const int64_t *bp_off, int32_t *bp_out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_bp_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, subset, qb, pg, sc, first_flag,
-                     ntrace, tier_of, trace, bp_off, bp_out);
+                     ntrace, tier_of, trace, lt, bp_off, bp_out);
   return hipGetLastError();
 }
 

@@ -220,6 +220,18 @@ constexpr int kTraceCap = 32;
 // ids of the gapped kernels a hit can be completed by (tier_out): LDS tiers 0..3, then the
 // wavefront-per-hit kernel with its state in HBM scratch
 constexpr int kLdsTiers = 4, kWaveTier = 4;
+// Long traces: the wavefront-per-hit kernel (mode 0) leaves the whole traceback chain of a direction it ran - cells as
+// i | j << 16 - in a pool of its own, trace[(2 * slot[x] + direction) * cap ...], and count[2 * slot[x] + direction] = its
+// length (-1: the direction was not run by this kernel - an LDS tier's trace slot has it -, -2: longer than cap).  A hit
+// whose two chains are all there is reported as kLongTraceTier instead of kWaveTier, and launch_bp_expand writes its pairs
+// from them: no second extension of the ~150 longest hits of a query (2 - 3 ms on an otherwise idle GPU).
+constexpr int kLongTraceTier = 5;
+struct LongTrace {
+  uint32_t *trace = nullptr;
+  int32_t *count = nullptr;
+  const int32_t *slot = nullptr; // per hit x; -1: none
+  int32_t cap = 0;
+};
 // tier_out[x] of a hit whose first direction is done and whose second one is somebody else's business: out.*[x] and
 // bp_count[x] hold its state after direction 0.  kResumeMark: the next kernel of the cascade extends the other
 // direction (a hit that outgrew a kernel in direction 1, or that the front kernel handed on with a first direction that
@@ -243,13 +255,15 @@ hipError_t launch_gapped_front(const HitSoA &in, HitSoA out, int64_t n, const ui
                                unsigned long long *next_work, void *scratch, hipStream_t s);
 hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                             const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
-                            const uint16_t *trace, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
+                            const uint16_t *trace, const LongTrace &lt, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);
 hipError_t launch_bp_count(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                            const SearchConst &sc, const int32_t *ntrace, int32_t *bp_count, hipStream_t s);
 hipError_t launch_bp_ends(const int64_t *bp_off, int64_t n, const int32_t *bp, int32_t *ends, hipStream_t s);
 hipError_t launch_gapped_wave(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb,
                               const PageDev &pg, const SearchConst &sc, ExtOpts o, GapScratch scratch, int mode,
                               uint8_t *overflow, uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count,
-                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s, int handover = 0);
+                              const int64_t *bp_off, int32_t *bp_out, hipStream_t s, int handover = 0,
+                              const LongTrace &lt = LongTrace{});
+hipError_t launch_assign_slots(const uint32_t *list, int64_t n, int32_t base, int32_t *slot, hipStream_t s); // slot[list[p]] = base + p
 
 } // namespace prb

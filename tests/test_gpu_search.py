@@ -163,7 +163,9 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
                                  "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_HANDOVER=0", "PRB_GAPPED_HANDOVER=0,PRB_GAPPED_NO_RESUME", "PRB_GAPPED_RESUME_CAP", "PRB_GAPPED_CHUNK_HITS=37", "PRB_GAPPED_CHUNK_HITS=500,PRB_TRACE_SLOT_CAP=1", "PRB_GAPPED_FRONT=0", "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=1", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
-                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS", "PRB_FILTER_TILES=0", "PRB_BIG_LIST_BYTES=1",
+                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS", "PRB_FILTER_TILES=0", "PRB_BIG_LIST_BYTES=1", "PRB_TRACE_NO_LONG", "PRB_GAPPED_FIRST_TIER=4,PRB_TRACE_NO_LONG",
+                                 "PRB_GAPPED_FIRST_TIER=4,PRB_TRACE_LONG_CAP=2", "PRB_GAPPED_FIRST_TIER=3,PRB_TRACE_LONG_CAP=1",
+                                 "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_CHUNK_HITS=300",
                                  "PRB_BIG_LIST_BYTES=1,PRB_GAPPED_CHUNK_HITS=500,PRB_SEARCH_CHUNK_PAIRS=20000"])
 def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     """Every hit through the wave-per-hit HBM-scratch kernel / the tier-3 / the tier-2 / the tier-1
@@ -175,7 +177,8 @@ def test_fallback_kernels_match_tier1(ctx, golden_dir, monkeypatch, env):
     the gapped stage run in chunks of a few hits (PRB_GAPPED_CHUNK_HITS,
     also with the final hits' pairs from a second extension: the kept lists are what that reads); likewise re-extending the final
     hits (all, or those with more than one traced pair per side) instead of reading their
-    base pairs from the trace slots of the extension pass; likewise the general four-key sort
+    base pairs from the trace slots of the extension pass, and the hits of the wavefront-per-hit kernel with or without their
+    long traces (PRB_TRACE_NO_LONG, PRB_TRACE_LONG_CAP: the default has them; PRB_GAPPED_FIRST_TIER=4 sends every hit there); likewise the general four-key sort
     instead of the one-key sort + tie pass; likewise tier 0 with one anti-diagonal per step instead of two; likewise
     the wavefront-per-hit kernel with its state in HBM scratch instead
     of LDS (what it uses when the state outgrows 64 KB); likewise the seeds written as a list and extended in a second pass
