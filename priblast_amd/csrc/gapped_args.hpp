@@ -72,6 +72,7 @@ struct GapArgs {
   GapResume rin, rout;
   LongTrace lt;     // mode 0, the wavefront-per-hit kernel: where it leaves whole traceback chains (search_kernels.hpp)
   int period = 0;   // LDS tiers: lockstep iterations between the boundaries at which groups change direction / hit (0: the drop-out length)
+  int early = 0;    // LDS tiers: a boundary also as soon as this many groups of the wavefront have finished their direction (0: never)
   int handover = 0; // mode 0, LDS tiers and the wavefront-per-hit kernel: stop behind a first direction that this kernel ran (kHandoverMark)
 };
 

@@ -1366,6 +1366,8 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
   const SeqBases sb{a.qb.enc, a.qb.acc, a.qb.cond, a.pg.acc, a.pg.cond};
   while (__ballot(phase != kDone) != 0) {
     GP_MARK(14);
+    // (a.early: not only every `period` iterations, but as soon as that many groups wait for a boundary)
+    if (a.early > 0 && tick != 0 && __popcll(__ballot(phase == kFinished)) >= a.early * G) tick = 0;
     if (tick == 0) {
       if (phase == kFinished) {
         DirResult r{true, 0};
@@ -1558,6 +1560,15 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
     int p[4] = {0, 0, 0, 0};
     sscanf(pe, "%d,%d,%d,%d", &p[0], &p[1], &p[2], &p[3]);
     a.period = mode == 0 && tier >= 0 && tier < 4 ? p[tier] : 0;
+  }
+  // Tier 2's four groups per wavefront hold hits that arrive in the middle of a direction and end anywhere: a boundary as soon as
+  // two of them wait costs it 220 ms per configs[2] step instead of 238 (tiers 0 and 1, eight groups: 2 - 4 waiting groups cost
+  // more in transitions than they save in waiting; tier 3 has one group per wavefront and waits for nobody).
+  a.early = tier == 2 ? 2 : 0;
+  if (const char *ee = getenv("PRB_GAPPED_EARLY")) { // experiment: "k0,k1,k2,k3" groups waiting that make a boundary, per tier
+    int k[4] = {0, 0, 0, 0};
+    sscanf(ee, "%d,%d,%d,%d", &k[0], &k[1], &k[2], &k[3]);
+    a.early = tier >= 0 && tier < 4 ? k[tier] : 0;
   }
   if (tier == 0) return launch_tier<Tier0, Rec32>(a, mode, s);
   if (tier == 1) return launch_tier<Tier1, Rec32>(a, mode, s);
