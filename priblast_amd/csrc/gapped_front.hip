@@ -68,8 +68,8 @@ constexpr int kFR = PRB_FRONT_RING;            // cells per direction, the start
 constexpr int kFWaves = 1;         // wavefronts per workgroup: one
 // Directions per wavefront.  The per-direction phases leave the lanes beyond them idle, the pooled phases use all 64; a
 // wavefront's time is the latency of its chain of phases (LDS and L2 round trips), so what counts is how many wavefronts a
-// compute unit holds: 64 directions = 22 KB of LDS = 7 wavefronts per compute unit, 27 ms per configs[2] launch; 32
-// directions = 12 KB = 12 wavefronts (then the registers are the limit).
+// compute unit holds: 64 directions = 19 KB of LDS (with the cells' energies pooled, see FrontLds) = 8 wavefronts per
+// compute unit; 32 directions = twice as many (then the registers are the limit), which was slower.
 constexpr int kFDirs = 64;
 constexpr int kFCells = 192;      // filled cells of a wavefront's directions in one step (two anti-diagonals)
 constexpr int kFPairs = 256;      // (cell, candidate) pairs in one round of at most 64 cells
@@ -89,11 +89,33 @@ struct FrontAcc {
   double eq[kFD][kFDirs], ed[kFD][kFDirs];
 };
 
+// The energies of the cells (8 of a record's 12 bytes) are pooled over the wavefront's 64 directions: a direction may fill
+// kFR cells, the average one fills eleven, so kFPool entries - the start cells first, then every step's cells in list order -
+// stand in for 64 x kFR: 19 KB of LDS per wavefront instead of 24.7, eight wavefronts per compute unit instead of six (what
+// bounds the kernel is the latency of a wavefront's chain of phases).  A record holds its pool index; a step whose cells
+// do not all fit gives up the directions of those that do not, as for a direction with more than kFR cells.
+#ifndef PRB_FRONT_POOL
+#define PRB_FRONT_POOL 832
+#endif
+constexpr int kFPool = PRB_FRONT_POOL;
+static_assert(kFPool >= 2 * kFDirs && kFPool <= 1024, "FRec::pool");
+struct FRec { // i:5 | j:5 | pool:10 | type:3 | qa:3 | da:3 (Rec32 with the pool index of the cell's energy for a predecessor)
+  static __device__ __forceinline__ uint32_t pack(int i, int j, int pool, int type, int qa, int da) {
+    return (uint32_t)i | ((uint32_t)j << 5) | ((uint32_t)pool << 10) | ((uint32_t)type << 20) | ((uint32_t)qa << 23) | ((uint32_t)da << 26);
+  }
+  static __device__ __forceinline__ int i(uint32_t v) { return v & 31; }
+  static __device__ __forceinline__ int j(uint32_t v) { return (v >> 5) & 31; }
+  static __device__ __forceinline__ int pool(uint32_t v) { return (v >> 10) & 1023; }
+  static __device__ __forceinline__ int type(uint32_t v) { return (v >> 20) & 7; }
+  static __device__ __forceinline__ int qa(uint32_t v) { return (v >> 23) & 7; }
+  static __device__ __forceinline__ int da(uint32_t v) { return (v >> 26) & 7; }
+};
+
 struct FrontLds { // per wavefront; arrays per direction are [slot][lane]: conflict-free whatever slot a lane is at
-  double hyb[kFR][kFDirs];
+  double hyb[kFPool]; // (pooled: FRec::pool)
   double te[kFPairs];
   int32_t tab[FrontTab::kCount];
-  uint32_t info[kFR][kFDirs]; // Rec32 (pred unused)
+  uint32_t info[kFR][kFDirs]; // FRec
   uint32_t cells[kFCells]; // direction lane | i << 8 | second anti-diagonal of the step << 13 | record index << 16
   uint32_t wp[2][kFDirs], fp[2][kFDirs]; // per direction, per anti-diagonal of the step: cells whose stored type is a wobble / is not 0
   uint32_t improved[kFDirs];
@@ -351,11 +373,12 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
       }
     }
     if (isdir) {
-      S.hyb[0][lane] = e_tot;
-      S.info[0][lane] = Rec32::pack(0, 0, 0, type0, q1, d1);
+      S.hyb[lane] = e_tot;
+      S.info[0][lane] = FRec::pack(0, 0, lane, type0, q1, d1);
       S.improved[lane] = 0;
     }
     int nrec = 1;
+    int pool_used = kFDirs; // (wave-uniform)
     // cells of anti-diagonals L - 2 and L - 1 whose stored type (Cell::type = the predecessor's) is not 0 / is a wobble
     uint32_t F2 = type0 != 0 ? 1u : 0u, W2 = wobble(type0) ? 1u : 0u, F1 = 0, W1 = 0;
     wave_mem_sync();
@@ -398,8 +421,8 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
       }
       int total;
       int base = wave_excl_scan(cnt, lane, total);
-      if (total > kFCells) { // (next to never: 64 directions with 4+ cells each on two anti-diagonals)
-        if (base + cnt > kFCells) {
+      if (total > kFCells || pool_used + total > kFPool) { // (next to never: 64 directions with 4+ cells each on two anti-diagonals, or 13+ each so far)
+        if (base + cnt > kFCells || pool_used + base + cnt > kFPool) {
           dead = true;
           fA = fB = 0;
           cnt = 0;
@@ -451,12 +474,13 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
         const int nscan = has ? nrecb : 0;
         for (int k = 0; __ballot(k < nscan) != 0; k += 2) { // (two records per turn: their reads are in flight together)
           const uint32_t v0 = S.info[k][dl], v1 = S.info[k + 1 < kFR ? k + 1 : k][dl];
-          if (k < nscan && Rec32::i(v0) < ci && Rec32::j(v0) < cj) qmask |= 1u << k;
-          if (k + 1 < nscan && Rec32::i(v1) < ci && Rec32::j(v1) < cj) qmask |= 2u << k;
+          if (k < nscan && FRec::i(v0) < ci && FRec::j(v0) < cj) qmask |= 1u << k;
+          if (k + 1 < nscan && FRec::i(v1) < ci && FRec::j(v1) < cj) qmask |= 2u << k;
         }
         const uint32_t cdw = (uint32_t)ci | ((uint32_t)cj << 5) | ((uint32_t)ctype << 10) | ((uint32_t)nq << 13) | ((uint32_t)nd << 16) |
                              ((uint32_t)dl << 19);
-        if (has) S.info[rec][dl] = Rec32::pack(ci, cj, 0, rtype_of(ctype), fq, fd);
+        const int pool = pool_used + c0 + lane; // the cell's place in the pool: its place in the step's list
+        if (has) S.info[rec][dl] = FRec::pack(ci, cj, pool, rtype_of(ctype), fq, fd);
         FP_MARK(6);
         int npc = __popc(qmask), ptotal;
         int poff = wave_excl_scan(npc, lane, ptotal);
@@ -482,8 +506,8 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
                       pdl = (cdv >> 19) & 63;
             const bool pf0 = (pdl & 1) == 0;
             const uint32_t v = S.info[k][pdl];
-            const double hk = S.hyb[k][pdl];
-            const int ri = Rec32::i(v), rj = Rec32::j(v), rq = Rec32::qa(v), rd = Rec32::da(v), rt = Rec32::type(v);
+            const double hk = S.hyb[FRec::pool(v)]; // (needed last: the read is under way while the loop energy is looked up)
+            const int ri = FRec::i(v), rj = FRec::j(v), rq = FRec::qa(v), rd = FRec::da(v), rt = FRec::type(v);
             double te = loop_energy_front(sc, S.tab, pf0 ? pct : rt, pf0 ? rt : pct, pci - ri - 1, pcj - rj - 1, pf0 ? pnq : rq,
                                           pf0 ? pnd : rd, pf0 ? rq : pnq, pf0 ? rd : pnd);
             te += hk;
@@ -505,12 +529,12 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
             }
           }
           // (the start cell is a candidate of every cell, so there is a best one; its type is what the cell stores)
-          const int ptype = Rec32::type(S.info[bk][dl]);
-          S.hyb[rec][dl] = bte;
+          const int ptype = FRec::type(S.info[bk][dl]);
+          S.hyb[pool] = bte;
           if (ptype != 0) atomicOr(&S.fp[isB][dl], 1u << ci);
           if (wobble(ptype)) atomicOr(&S.wp[isB][dl], 1u << ci);
           const double ie = eqc + edc + bte;
-          const double min_e = S.hyb[0][dl]; // the hit's energy: nothing has improved on it so far
+          const double min_e = S.hyb[dl]; // the hit's energy (the start cell's entry): nothing has improved on it so far
           if (ie < min_e) S.improved[dl] = 1;
         }
         wave_lds_sync();
@@ -519,6 +543,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
       }
       // ---- per direction again: what the next anti-diagonals' checks need ----
       nrec += cnt;
+      pool_used += total;
       F2 = S.fp[0][me];
       W2 = S.wp[0][me];
       F1 = S.fp[1][me];
