@@ -72,7 +72,10 @@ constexpr int kFWaves = 1;         // wavefronts per workgroup: one
 // compute unit; 32 directions = twice as many (then the registers are the limit), which was slower.
 constexpr int kFDirs = 64;
 constexpr int kFCells = 192;      // filled cells of a wavefront's directions in one step (two anti-diagonals)
-constexpr int kFPairs = 256;      // (cell, candidate) pairs in one round of at most 64 cells
+#ifndef PRB_FRONT_PAIRS
+#define PRB_FRONT_PAIRS 256
+#endif
+constexpr int kFPairs = PRB_FRONT_PAIRS;      // (cell, candidate) pairs in one round of at most 64 cells
 
 // the part of SearchTab every loop class but the 1x1 / 1x2 / 2x1 / 2x2 interior loops reads from, staged in LDS
 struct FrontTab {
@@ -99,6 +102,7 @@ struct FrontAcc {
 #endif
 constexpr int kFPool = PRB_FRONT_POOL;
 static_assert(kFPool >= 2 * kFDirs && kFPool <= 1024, "FRec::pool");
+static_assert(kFrontMaxDrop <= 16, "FrontLds::wfp: 16 cells per anti-diagonal");
 struct FRec { // i:5 | j:5 | pool:10 | type:3 | qa:3 | da:3 (Rec32 with the pool index of the cell's energy for a predecessor)
   static __device__ __forceinline__ uint32_t pack(int i, int j, int pool, int type, int qa, int da) {
     return (uint32_t)i | ((uint32_t)j << 5) | ((uint32_t)pool << 10) | ((uint32_t)type << 20) | ((uint32_t)qa << 23) | ((uint32_t)da << 26);
@@ -117,8 +121,8 @@ struct FrontLds { // per wavefront; arrays per direction are [slot][lane]: confl
   int32_t tab[FrontTab::kCount];
   uint32_t info[kFR][kFDirs]; // FRec
   uint32_t cells[kFCells]; // direction lane | i << 8 | second anti-diagonal of the step << 13 | record index << 16
-  uint32_t wp[2][kFDirs], fp[2][kFDirs]; // per direction, per anti-diagonal of the step: cells whose stored type is a wobble / is not 0
-  uint32_t improved[kFDirs];
+  uint32_t wfp[2][kFDirs]; // per direction, per anti-diagonal of the step: cells (bit i - 1) whose stored type is not 0, << 16: is a wobble
+  uint8_t improved[kFDirs];
   uint32_t pairs[kFPairs]; // the cell: ci | cj << 5 | ctype << 10 | nq << 13 | nd << 16 | direction lane << 19; candidate << 25
 };
 
@@ -436,10 +440,8 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
           S.cells[base + r] = (uint32_t)lane | ((uint32_t)__builtin_ctz(m) << 8) | (1u << 13) | ((uint32_t)(nrec + r) << 16);
       }
       if (isdir) {
-        S.wp[0][lane] = 0;
-        S.wp[1][lane] = 0;
-        S.fp[0][lane] = 0;
-        S.fp[1][lane] = 0;
+        S.wfp[0][lane] = 0;
+        S.wfp[1][lane] = 0;
       }
       wave_lds_sync();
       FP_MARK(5);
@@ -531,8 +533,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
           // (the start cell is a candidate of every cell, so there is a best one; its type is what the cell stores)
           const int ptype = FRec::type(S.info[bk][dl]);
           S.hyb[pool] = bte;
-          if (ptype != 0) atomicOr(&S.fp[isB][dl], 1u << ci);
-          if (wobble(ptype)) atomicOr(&S.wp[isB][dl], 1u << ci);
+          if (ptype != 0) atomicOr(&S.wfp[isB][dl], (wobble(ptype) ? 0x10001u : 1u) << (ci - 1)); // (a cell has 1 <= i <= 16)
           const double ie = eqc + edc + bte;
           const double min_e = S.hyb[dl]; // the hit's energy (the start cell's entry): nothing has improved on it so far
           if (ie < min_e) S.improved[dl] = 1;
@@ -544,16 +545,23 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
       // ---- per direction again: what the next anti-diagonals' checks need ----
       nrec += cnt;
       pool_used += total;
-      F2 = S.fp[0][me];
-      W2 = S.wp[0][me];
-      F1 = S.fp[1][me];
-      W1 = S.wp[1][me];
+      {
+        const uint32_t m0 = S.wfp[0][me], m1 = S.wfp[1][me];
+        F2 = (m0 & 0xFFFFu) << 1;
+        W2 = (m0 >> 16) << 1;
+        F1 = (m1 & 0xFFFFu) << 1;
+        W1 = (m1 >> 16) << 1;
+      }
       FP_COUNT(22, __popcll(__ballot(!dead && S.improved[me] != 0)));
       if (S.improved[me]) dead = true;
       FP_MARK(10);
       // (the next step's LA - 2 and LA - 1 are this step's two anti-diagonals: F2 / W2 and F1 / W1 as just set)
     }
 
+    FP_COUNT(23, pool_used > 640);
+    FP_COUNT(24, pool_used > 704);
+    FP_COUNT(25, pool_used > 768);
+    FP_COUNT(26, pool_used);
     FP_MARK(11);
     // ---- the hit: done when neither direction finds anything (GappedExtension::Run tail, :49-67) ----
     const bool ok = live && (!dead || (resumed && f0));

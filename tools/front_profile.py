@@ -45,6 +45,7 @@ def main():
     print(f"tiles {tiles:.0f}, {cyc / tiles:.0f} wave-cycles per tile; steps per tile {steps / tiles:.2f}, rounds per step {rounds / steps:.2f}, "
           f"cells per step {cells / steps:.1f}, pairs per round {pairs / rounds:.1f}, pairs per cell {pairs / cells:.2f}")
     print(f"directions given up: too many cells {v[21]:.0f}, improved {v[22]:.0f} ")
+    print(f"pool entries used per tile: {v[26] / tiles:.0f} on average; tiles with more than 640 / 704 / 768: {v[23] / tiles * 100:.2f} / {v[24] / tiles * 100:.2f} / {v[25] / tiles * 100:.2f} %")
     for i, name in enumerate(REGIONS):
         print(f"  {name:36s} {v[i] / cyc * 100:6.2f} %   {v[i] / tiles:9.0f} cycles per tile")
 

@@ -23,7 +23,7 @@ else
 import json, sys
 d = json.load(open('$HERE/gpurun_out/geo.json'))
 s = d['stage_ms_per_step']
-print('$(basename $so)', round(d['ms_per_step']), {k: round(s[k]) for k in ('gapped', 'gapped_t1', 'gapped_t2', 'gapped_t3', 'gapped_slow')}, flush=True)
+print('$(basename $so)', round(d['ms_per_step']), {k: round(s[k]) for k in ('gapped_front', 'gapped', 'gapped_t1', 'gapped_t2', 'gapped_t3', 'gapped_slow')}, flush=True)
 "
   done
 fi
