@@ -48,7 +48,7 @@ struct PageMem {
 struct SearchWs {
   DevBuf cands, row_count, row_off, hitsA, hitsB, hitsC, hitsTmp, kE, kL, kQ, kP, kTmp, kTmp2, idxA, idxB, sortTmp, endKey, pmax,
       state, keep, pending, surv, count, first, gapScratch, overflow, subset, subset2, cidx, ntrace, bpCount, bpOff, bpOut, bpEnds, bpCount2, bpOff2,
-      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, listC, slowList, slowSlot, slowCnt, slowTrace, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
+      scanTmp, tierOf, tierFin, listA, listB, trace, ntraceFin, packed, row_cand, seed_qacc, resumeSlot, resumePool, resumePool2, resumePool3, resumeCount, frontScratch, accScratch, listC, slowList, slowSlot, slowCnt, slowTrace, keptU, keptFirst, keptTier, keptNtrace, keptTrace;
   // The front of the one-pass seed path for a chunk of candidates - candidates and their pair offsets on the device,
   // query-side window sums, the pairs' keys and values, sorted - in buffers of its own, so that it can be issued for
   // the NEXT sub-batch, on a stream of its own, while this sub-batch is in its last, nearly idle stretch (search_range):
@@ -116,7 +116,7 @@ struct SearchWs {
   void release() {
     for (DevBuf *b : {&cands, &row_count, &row_off, &hitsA, &hitsB, &hitsC, &hitsTmp, &kE, &kL, &kQ, &kP, &kTmp, &kTmp2, &idxA, &idxB,
                       &sortTmp, &endKey, &pmax, &state, &keep, &pending, &surv, &count, &first, &gapScratch, &overflow,
-                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &listC, &slowList, &slowSlot, &slowCnt, &slowTrace, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
+                      &subset, &subset2, &cidx, &ntrace, &bpCount, &bpOff, &bpOut, &bpEnds, &bpCount2, &bpOff2, &scanTmp, &tierOf, &tierFin, &listA, &listB, &trace, &ntraceFin, &packed, &row_cand, &seed_qacc, &resumeSlot, &resumePool, &resumePool2, &resumePool3, &resumeCount, &frontScratch, &accScratch, &listC, &slowList, &slowSlot, &slowCnt, &slowTrace, &keptU, &keptFirst, &keptTier, &keptNtrace, &keptTrace})
       b->release();
     front.release();
     if (copy_stream) {
@@ -1521,6 +1521,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
   // the cascade for the chunk (U, G, nch, firstc)
   auto extend_chunk = [&]() -> int {
   const int64_t nung = nch; // (everything below is per chunk)
+  if ((rc = w.accScratch.ensure(std::max<size_t>(gapped_acc_scratch_bytes(), 8)))) return rc;
   PRB_HIP(hipMemsetAsync(w.tierOf.p, 0, (size_t)nung, ctx->stream)); // no hit carries a resume mark yet
   // state dumps for the hits that outgrow tier 0 (~15 %: room for one hit in four, at most 4 M), tier 1
   // (~4 %: one in eight, at most 2 M) and tier 2 (~0.7 %: one in 32, at most 1 M); rs[t] = dumps of tier t
@@ -1587,7 +1588,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
           PRB_HIP(launch_gapped_lds(U, G, m, cur, qb->view, pd, sc, eo, 0, tier, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
                                     firstc, w.ntrace.as<int32_t>(), w.trace.as<uint16_t>(), nullptr, nullptr,
                                     w.count.as<unsigned long long>() + 1, tier >= 1 ? rs[tier - 1] : no_resume,
-                                    tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream, handover));
+                                    tier < kLdsTiers - 1 ? rs[tier] : no_resume, ctx->stream, handover, w.accScratch.as<double>()));
           int64_t rest = 0;
           if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
           if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[tier %d%s] hits %lld, go on %lld\n", tier, handover ? ", first direction" : "", (long long)m, (long long)rest);
@@ -1828,7 +1829,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
         PRB_HIP(launch_gapped_lds(U, G, m, w.subset2.as<uint32_t>(), qb->view, pd, sc, eo, 2, t, nullptr, nullptr,
                                   first_all, nullptr, nullptr, w.bpOff2.as<int64_t>(), w.bpOut.as<int32_t>(),
                                   w.count.as<unsigned long long>() + 1, GapResume{nullptr, nullptr, nullptr, 0},
-                                  GapResume{nullptr, nullptr, nullptr, 0}, ctx->stream));
+                                  GapResume{nullptr, nullptr, nullptr, 0}, ctx->stream, 0, w.accScratch.as<double>()));
       }
       PRB_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are reused by the next tier
     }

@@ -71,6 +71,7 @@ struct GapArgs {
   // (slot[x] = -1: none): `rin` = what this kernel may continue, `rout` = where it leaves its own
   GapResume rin, rout;
   LongTrace lt;     // mode 0, the wavefront-per-hit kernel: where it leaves whole traceback chains (search_kernels.hpp)
+  double *acc_scratch = nullptr; // LDS tiers 1 and 2: 2 x capacity doubles per resident group (gapped_acc_scratch_bytes)
   int period = 0;   // LDS tiers: lockstep iterations between the boundaries at which groups change direction / hit (0: the drop-out length)
   int early = 0;    // LDS tiers: a boundary also as soon as this many groups of the wavefront have finished their direction (0: never)
   int handover = 0; // mode 0, LDS tiers and the wavefront-per-hit kernel: stop behind a first direction that this kernel ran (kHandoverMark)

@@ -81,26 +81,35 @@ struct Tier0 { // 1,280 B per hit: 4 workgroups of 256 threads (32 hits) are exa
   static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by the next tier
   static constexpr bool kResumes = false;
   static constexpr bool kPairSteps = true; // two anti-diagonals per step where that is safe (dir_step_pair)
+  static constexpr bool kAccGlobal = false;
 };
+#ifndef PRB_T12_ACC_GLOBAL
+#define PRB_T12_ACC_GLOBAL true
+#endif
+#ifndef PRB_T12_WPS
+#define PRB_T12_WPS (PRB_T12_ACC_GLOBAL ? 4 : 3)
+#endif
 #ifndef PRB_T1_CAPD // (geometry experiments: tools/tier_geometry.sh)
 #define PRB_T1_CAPD 40
 #define PRB_T1_CAPR 64
 #define PRB_T1_GROUPS 32
-#define PRB_T1_WGCU 3
+#define PRB_T1_WGCU (PRB_T12_ACC_GLOBAL ? 4 : 3)
 #endif
 struct Tier1 { // 1.65 KB per hit, 3 workgroups of 256 threads (32 hits) per CU: the hits a little too long for tier 0
-  static constexpr int kG = 8, kCapD = PRB_T1_CAPD, kCapR = PRB_T1_CAPR, kGroups = PRB_T1_GROUPS, kWavesPerSimd = 3, kWgPerCu = PRB_T1_WGCU;
+  static constexpr int kG = 8, kCapD = PRB_T1_CAPD, kCapR = PRB_T1_CAPR, kGroups = PRB_T1_GROUPS, kWavesPerSimd = PRB_T12_WPS, kWgPerCu = PRB_T1_WGCU;
   static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 0, leaves its own
   using From = Tier0;
   using FromRec = Rec32;
   static constexpr bool kPairSteps = false;
+  static constexpr bool kAccGlobal = PRB_T12_ACC_GLOBAL; // the cumulative accessibility sums in a block of memory (L2) instead of LDS: see LdsLive
 };
 struct Tier2 { // 3.2 KB per hit, 3 workgroups of 256 threads (16 hits) per CU
-  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = 3, kWgPerCu = 3;
+  static constexpr int kG = 16, kCapD = 64, kCapR = 120, kGroups = 16, kWavesPerSimd = PRB_T12_WPS, kWgPerCu = PRB_T12_ACC_GLOBAL ? 4 : 3;
   static constexpr bool kResumable = true, kResumes = true; // continues the state dumps of tier 1, leaves its own
   using From = Tier1;
   using FromRec = Rec32;
   static constexpr bool kPairSteps = false;
+  static constexpr bool kAccGlobal = PRB_T12_ACC_GLOBAL;
 };
 struct Tier3 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgroups per CU
   static constexpr int kG = 64, kCapD = 128, kCapR = 512, kGroups = 1, kWavesPerSimd = 4, kWgPerCu = 16;
@@ -108,6 +117,7 @@ struct Tier3 { // 9.3 KB per hit, one wavefront per hit, 16 single-wave workgrou
   using From = Tier2;
   using FromRec = Rec32;
   static constexpr bool kPairSteps = false;
+  static constexpr bool kAccGlobal = false;
 };
 
 // A filled cell r is (i, j, pred = index of the predecessor cell, type = Stem::type,
@@ -154,15 +164,35 @@ template <class T, class Rec> struct LdsState {
   alignas(8) uint8_t ptab[3][kPtabLen];
   uint8_t qb[T::kCapD + 16], db[T::kCapD + 16]; // bases along the extension, 0 = end of sequence / masked
 };
+// What of it lives in LDS.  The cumulative accessibility sums - 16 B per anti-diagonal, a third of the state, written once per
+// 16 lengths and read twice per filled cell, behind its scan - of tiers 1 and 2 live in a block of memory per resident group
+// instead (it stays in L2): 1.0 / 1.8 KB of LDS per hit instead of 1.6 / 2.8, four wavefronts per SIMD instead of three
+// (these tiers are bound by latency, not by issue: a third fewer wavefronts cost them a third more time).
+template <class T, class Rec, bool kAccGlobal = T::kAccGlobal> struct LdsLive : LdsState<T, Rec> {};
+template <class T, class Rec> struct LdsLive<T, Rec, true> {
+  double hyb[T::kCapR];
+  typename Rec::word info[T::kCapR];
+  static constexpr int kPtabLen = (T::kCapD + 7) & ~7;
+  alignas(8) uint8_t ptab[3][kPtabLen];
+  uint8_t qb[T::kCapD + 16], db[T::kCapD + 16];
+};
 template <class T, class Rec> struct LdsStore {
   using R = Rec;
   static constexpr bool kResumable = T::kResumable;
+  static constexpr bool kAccGlobal = T::kAccGlobal;
   static constexpr int kCapD = T::kCapD;
-  LdsState<T, Rec> &s;
+  LdsLive<T, Rec> &s;
+  double *acc; // kAccGlobal: eq[kCapD], ed[kCapD] of this group
   __device__ __forceinline__ int cap_d() const { return T::kCapD; }
   __device__ __forceinline__ int cap_r() const { return T::kCapR; }
-  __device__ __forceinline__ double &eq(int i) const { return s.eq[i]; }
-  __device__ __forceinline__ double &ed(int i) const { return s.ed[i]; }
+  __device__ __forceinline__ double &eq(int i) const {
+    if constexpr (T::kAccGlobal) return acc[i];
+    else return s.eq[i];
+  }
+  __device__ __forceinline__ double &ed(int i) const {
+    if constexpr (T::kAccGlobal) return acc[T::kCapD + i];
+    else return s.ed[i];
+  }
   __device__ __forceinline__ double &hyb(int r) const { return s.hyb[r]; }
   __device__ __forceinline__ typename Rec::word &info(int r) const { return s.info[r]; }
   __device__ __forceinline__ uint8_t &ptab(int row, int i) const { return s.ptab[row][i]; }
@@ -174,6 +204,7 @@ template <class T, class Rec> struct LdsStore {
 struct HbmStore { // one block of the scratch per group
   using R = Rec64;
   static constexpr bool kResumable = false;
+  static constexpr bool kAccGlobal = false;
   double *eq_, *ed_, *hyb_;
   uint64_t *info_;
   uint8_t *ptab_, *qb_, *db_;
@@ -200,6 +231,15 @@ template <bool kLds> __device__ __forceinline__ void group_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+// behind writes of the accessibility sums when they live in memory (LdsStore::kAccGlobal): the other lanes' reads see them
+template <class Store> __device__ __forceinline__ void acc_sync() {
+  if constexpr (Store::kAccGlobal) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -353,6 +393,7 @@ __device__ __forceinline__ void stage_acc(const SeqBases &sb, const HitCtx &c, i
   }
   d.staged = L0 + nb - 1 < S.cap_d() ? L0 + nb - 1 : S.cap_d();
   group_sync<kLds>();
+  acc_sync<Store>();
 }
 
 // The same for the lengths beyond what dir_init prepared (one direction in ten gets here), when the
@@ -418,6 +459,7 @@ __device__ __forceinline__ void stage_acc_regs(const SeqBases &sb, const HitCtx 
   d.acc_prev = (G > 1 && gl == 1) ? ved : veq;
   d.staged = L0 + nb - 1 < S.cap_d() ? L0 + nb - 1 : S.cap_d();
   group_sync<kLds>();
+  acc_sync<Store>();
 }
 
 // Bases along the extension: window[t] = GetChar(seq, start -/+ t) (gapped_extension.cpp:401-407); the
@@ -1079,7 +1121,7 @@ template <class T, class Rec> constexpr size_t resume_bytes() {
 
 template <int G, class T, class Rec>
 __device__ __forceinline__ void resume_dump(const GapResume &ro, const HitCtx &c, const DirState &d, int flag,
-                                            const LdsState<T, Rec> &st, int gl, int gbase) {
+                                            const LdsStore<T, Rec> &S, int gl, int gbase) {
   int slot = -1;
   if (gl == 0) {
     slot = (int)atomicAdd(ro.count, 1u);
@@ -1098,10 +1140,25 @@ __device__ __forceinline__ void resume_dump(const GapResume &ro, const HitCtx &c
   } else if (gl == 1) {
     H->acc_prev1 = d.acc_prev;
   }
-  uint32_t *w = reinterpret_cast<uint32_t *>(dst + sizeof(ResumeHeader));
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(&st);
+  if constexpr (!T::kAccGlobal) { // the state as it lies in LDS, word by word
+    uint32_t *w = reinterpret_cast<uint32_t *>(dst + sizeof(ResumeHeader));
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&S.s);
 #pragma unroll 2 // (rare path: keep its registers out of the way)
-  for (int t = gl; t < (int)(sizeof(LdsState<T, Rec>) / 4); t += G) w[t] = src[t];
+    for (int t = gl; t < (int)(sizeof(LdsState<T, Rec>) / 4); t += G) w[t] = src[t];
+  } else { // what resume_load reads of it (the windows of bases are staged afresh there), in the same layout
+    LdsState<T, Rec> *o = reinterpret_cast<LdsState<T, Rec> *>(dst + sizeof(ResumeHeader));
+    for (int t = gl; t < T::kCapD; t += G) {
+      o->eq[t] = S.eq(t);
+      o->ed[t] = S.ed(t);
+    }
+    for (int t = gl; t < d.nrec; t += G) {
+      o->hyb[t] = S.hyb(t);
+      o->info[t] = S.info(t);
+    }
+    uint32_t *pw = reinterpret_cast<uint32_t *>(&o->ptab[0][0]);
+    const uint32_t *ps = reinterpret_cast<const uint32_t *>(&S.s.ptab[0][0]);
+    for (int t = gl; t < 3 * LdsState<T, Rec>::kPtabLen / 4; t += G) pw[t] = ps[t];
+  }
 }
 
 // Receiving side: the group's LDS state and scalars from a dump of the smaller tier TS (its own,
@@ -1136,6 +1193,7 @@ __device__ __forceinline__ void resume_load(const GapResume &ri, int slot, const
     S.ptab(row, i) = s0->ptab[row][i];
   }
   group_sync<true>();
+  acc_sync<Store>();
 }
 
 // Hit w of the work list.  kMode 0: extend, write the hit to out, the number of traced-back
@@ -1344,14 +1402,18 @@ __global__ __launch_bounds__(256) void k_bp_count(HitSoA in, int64_t n, const ui
 // (PROF build: with hit-by-hit lockstep 36 % of the wave time was spent waiting for the longest
 // extension; with free-running groups 40 % on each other's divergent transitions).
 template <int kMode, class T, class Rec, bool kPair>
+#ifdef PRB_TIERS_VGPR128 // (experiment: what the tiers cost at the registers of four wavefronts per SIMD)
+__global__ __launch_bounds__(T::kG *T::kGroups) __attribute__((amdgpu_num_vgpr(128))) void k_gapped_lds(GapArgs a) {
+#else
 __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_lds(GapArgs a) {
+#endif
   static_assert(!kPair || (T::kPairSteps && T::kG == 8), "dir_step_pair");
-  __shared__ LdsState<T, Rec> lds[T::kGroups];
+  __shared__ LdsLive<T, Rec> lds[T::kGroups];
   constexpr int G = T::kG;
   const int gl = threadIdx.x & (G - 1);
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
   const int gid = threadIdx.x / G;
-  const LdsStore<T, Rec> S{lds[gid]};
+  const LdsStore<T, Rec> S{lds[gid], T::kAccGlobal ? a.acc_scratch + ((size_t)blockIdx.x * T::kGroups + gid) * 2 * T::kCapD : nullptr};
   const int64_t ngroups = (int64_t)gridDim.x * T::kGroups;
   GapProf prof;
   prof.start();
@@ -1376,7 +1438,7 @@ __global__ __launch_bounds__(T::kG *T::kGroups, T::kWavesPerSimd) void k_gapped_
           r = dir_finish(d, c.h, flag, S); // (an overflowed direction leaves c.h as it was)
         } else {
           if constexpr (kMode == 0 && T::kResumable)
-            if (a.rout.slot) resume_dump<G, T, Rec>(a.rout, c, d, flag, lds[gid], gl, gbase);
+            if (a.rout.slot) resume_dump<G, T, Rec>(a.rout, c, d, flag, S, gl, gbase);
         }
         hit_dir_done<kMode, true>(a, c, flag, og, r, S, gl);
         group_sync<true>();
@@ -1522,6 +1584,14 @@ size_t gapped_resume_bytes(int tier) {
   return tier == 0 ? resume_bytes<Tier0, Rec32>() : tier == 1 ? resume_bytes<Tier1, Rec32>() : resume_bytes<Tier2, Rec32>();
 }
 
+// the block of memory launch_gapped_lds wants for the accessibility sums of the resident groups of tiers 1 / 2 (0: none)
+size_t gapped_acc_scratch_bytes() {
+  if (!Tier1::kAccGlobal) return 0;
+  const size_t t1 = (size_t)256 * Tier1::kWgPerCu * Tier1::kGroups * 2 * Tier1::kCapD * sizeof(double);
+  const size_t t2 = (size_t)256 * Tier2::kWgPerCu * Tier2::kGroups * 2 * Tier2::kCapD * sizeof(double);
+  return t1 > t2 ? t1 : t2;
+}
+
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
   size_t b = (size_t)cap_diag * 16 + (size_t)cap_rec * 16 + 3 * ((size_t)cap_diag + 4) + 2 * ((size_t)cap_diag + 16);
   return (b + 255) & ~(size_t)255;
@@ -1541,7 +1611,13 @@ template <class T, class Rec> hipError_t launch_tier(const GapArgs &a, int mode,
       return hipGetLastError();
     }
   }
-  if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec, false>), grid, blk, 0, s, a);
+  size_t pad = 0; // experiment (PRB_GAPPED_LDS_PAD="b1,b2,b3"): unused dynamic LDS per workgroup of tiers 1 - 3, i.e. fewer wavefronts per compute unit
+  if (const char *pe = getenv("PRB_GAPPED_LDS_PAD")) {
+    int b[4] = {0, 0, 0, 0};
+    sscanf(pe, "%d,%d,%d", &b[1], &b[2], &b[3]);
+    pad = (size_t)b[a.tier_id < 4 ? a.tier_id : 0];
+  }
+  if (mode == 0) hipLaunchKernelGGL((k_gapped_lds<0, T, Rec, false>), grid, blk, pad, s, a);
   else hipLaunchKernelGGL((k_gapped_lds<2, T, Rec, false>), grid, blk, 0, s, a);
   return hipGetLastError();
 }
@@ -1551,11 +1627,13 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
                              const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work, const GapResume &rin,
-                             const GapResume &rout, hipStream_t s, int handover) {
+                             const GapResume &rout, hipStream_t s, int handover, double *acc_scratch) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,   n,      subset, qb,        pg,         sc, o, overflow, tier_out, tier, first_flag, bp_count,
             trace,   bp_off, bp_out, next_work, rin,     rout};
   a.handover = mode == 0 ? handover : 0;
+  a.acc_scratch = acc_scratch;
+  if ((tier == 1 || tier == 2) && Tier1::kAccGlobal && !acc_scratch) return hipErrorInvalidValue;
   if (const char *pe = getenv("PRB_GAPPED_PERIOD")) { // experiment: "p0,p1,p2,p3" lockstep iterations between boundaries, per tier (0: default)
     int p[4] = {0, 0, 0, 0};
     sscanf(pe, "%d,%d,%d,%d", &p[0], &p[1], &p[2], &p[3]);

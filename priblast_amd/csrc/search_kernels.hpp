@@ -211,7 +211,9 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
                              const PageDev &pg, const SearchConst &sc, ExtOpts o, int mode, int tier, uint8_t *overflow,
                              uint8_t *tier_out, const uint8_t *first_flag, int32_t *bp_count, uint16_t *trace,
                              const int64_t *bp_off, int32_t *bp_out, unsigned long long *next_work /* 8 bytes of scratch */,
-                             const GapResume &rin, const GapResume &rout, hipStream_t s, int handover = 0 /* GapArgs::handover */);
+                             const GapResume &rin, const GapResume &rout, hipStream_t s, int handover = 0 /* GapArgs::handover */,
+                             double *acc_scratch = nullptr /* gapped_acc_scratch_bytes() of device memory */);
+size_t gapped_acc_scratch_bytes();
 // Trace slots: the extension pass (mode 0, LDS tiers) leaves the first kTraceCap cells (i | j << 8)
 // of each direction's traceback chain of hit x at trace[(2x + direction) * kTraceCap ...];
 // launch_bp_expand writes the base pairs of the final hits from them (hits of the wave kernel or
