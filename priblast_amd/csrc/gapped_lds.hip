@@ -77,11 +77,18 @@ constexpr int kInitStage = 16; // extension lengths whose accessibility sums dir
 // workgroup, staged extension lengths (<= lanes per hit)
 struct Tier0 { // 1,280 B per hit: 4 workgroups of 256 threads (32 hits) are exactly the 160 KB of a CU = 4 wavefronts per SIMD
                // (32 anti-diagonals instead of 30: 16 % fewer hits go on to tier 1, -40 ms per configs[2] step)
-  static constexpr int kG = 8, kCapD = 32, kCapR = 48, kGroups = 32, kWavesPerSimd = 4, kWgPerCu = 4;
+#ifndef PRB_T0_CAPR
+#define PRB_T0_CAPR 48
+#define PRB_T0_WGCU 4
+#endif
+#ifndef PRB_T0_ACC_GLOBAL
+#define PRB_T0_ACC_GLOBAL false
+#endif
+  static constexpr int kG = 8, kCapD = 32, kCapR = PRB_T0_CAPR, kGroups = 32, kWavesPerSimd = PRB_T0_WGCU, kWgPerCu = PRB_T0_WGCU;
   static constexpr bool kResumable = true; // a hit that outgrows it is continued, not redone, by the next tier
   static constexpr bool kResumes = false;
   static constexpr bool kPairSteps = true; // two anti-diagonals per step where that is safe (dir_step_pair)
-  static constexpr bool kAccGlobal = false;
+  static constexpr bool kAccGlobal = PRB_T0_ACC_GLOBAL;
 };
 #ifndef PRB_T12_ACC_GLOBAL
 #define PRB_T12_ACC_GLOBAL true
@@ -1586,10 +1593,11 @@ size_t gapped_resume_bytes(int tier) {
 
 // the block of memory launch_gapped_lds wants for the accessibility sums of the resident groups of tiers 1 / 2 (0: none)
 size_t gapped_acc_scratch_bytes() {
-  if (!Tier1::kAccGlobal) return 0;
+  if (!Tier1::kAccGlobal && !Tier0::kAccGlobal) return 0;
+  const size_t t0 = (size_t)256 * Tier0::kWgPerCu * Tier0::kGroups * 2 * Tier0::kCapD * sizeof(double);
   const size_t t1 = (size_t)256 * Tier1::kWgPerCu * Tier1::kGroups * 2 * Tier1::kCapD * sizeof(double);
   const size_t t2 = (size_t)256 * Tier2::kWgPerCu * Tier2::kGroups * 2 * Tier2::kCapD * sizeof(double);
-  return t1 > t2 ? t1 : t2;
+  return std::max(t0, std::max(t1, t2));
 }
 
 size_t gapped_wave_scratch_bytes(int cap_diag, int cap_rec) {
@@ -1633,7 +1641,7 @@ hipError_t launch_gapped_lds(const HitSoA &in, HitSoA out, int64_t n, const uint
             trace,   bp_off, bp_out, next_work, rin,     rout};
   a.handover = mode == 0 ? handover : 0;
   a.acc_scratch = acc_scratch;
-  if ((tier == 1 || tier == 2) && Tier1::kAccGlobal && !acc_scratch) return hipErrorInvalidValue;
+  if (((tier == 1 || tier == 2) && Tier1::kAccGlobal || tier == 0 && Tier0::kAccGlobal) && !acc_scratch) return hipErrorInvalidValue;
   if (const char *pe = getenv("PRB_GAPPED_PERIOD")) { // experiment: "p0,p1,p2,p3" lockstep iterations between boundaries, per tier (0: default)
     int p[4] = {0, 0, 0, 0};
     sscanf(pe, "%d,%d,%d,%d", &p[0], &p[1], &p[2], &p[3]);
