@@ -1550,11 +1550,12 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
     uint32_t *bufs[2] = {w.listA.as<uint32_t>(), w.listB.as<uint32_t>()};
     int nb = 0;
     // the front kernel on the list (cur, m): what it completes leaves the list
-    auto run_front = [&]() -> int {
+    auto run_front = [&](bool second_only = false) -> int {
       if ((rc = w.frontScratch.ensure(gapped_front_scratch_bytes()))) return rc;
       if ((rc = ctx->time_begin())) return rc;
       PRB_HIP(launch_gapped_front(U, G, m, cur, qb->view, pd, sc, eo, 0, w.overflow.as<uint8_t>(), w.tierOf.as<uint8_t>(),
-                                  w.ntrace.as<int32_t>(), w.count.as<unsigned long long>() + 1, w.frontScratch.p, ctx->stream));
+                                  w.ntrace.as<int32_t>(), w.count.as<unsigned long long>() + 1, w.frontScratch.p, ctx->stream,
+                                  second_only && !getenv("PRB_GAPPED_FRONT_PAIRED")));
       int64_t rest = 0;
       if ((rc = select_overflow(cur, m, bufs[nb], &rest))) return rc;
       if (getenv("PRB_DEBUG_ROWS")) fprintf(stderr, "[front] hits %lld, go on %lld\n", (long long)m, (long long)rest);
@@ -1645,7 +1646,7 @@ static int search_range(prb_ctx *ctx, prb_qbatch *qb, prb_db *db, int page, cons
           PRB_HIP(hipMemsetAsync(w.resumeCount.p, 0, 16, ctx->stream));
           PRB_HIP(hipMemsetAsync(w.resumeSlot.p, 0xFF, (size_t)nung * 4 * 3, ctx->stream));
         }
-        if ((rc = run_front())) return rc;
+        if ((rc = run_front(true))) return rc; // (all of them stopped behind their first direction: a lane per hit)
         if ((rc = run_cascade(0, true))) return rc;
       }
       if (n_slow + m > 0) {

@@ -254,6 +254,9 @@ __device__ __forceinline__ double loop_energy_front(const SearchConst &sc, const
   return div100(sc, z1v + lt[i2] + lt[i3]);
 }
 
+// kOneDir: every hit of the list has its first direction behind it (the cascade's second pass): a lane per hit, all of them
+// second directions - 64 hits per wavefront instead of 32 with half the lanes out of the proof from the start.
+template <bool kOneDir>
 __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontAcc *acc_blocks) {
   __shared__ FrontLds lds[kFWaves];
   const int lane = threadIdx.x & 63;
@@ -265,11 +268,11 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
                : t < FrontTab::kTau     ? sc.tab[SearchTab::kBulge + (t - FrontTab::kBulge)]
                : t < FrontTab::kZero    ? sc.tab[SearchTab::kTau + (t - FrontTab::kTau)]
                                         : 0;
-  const int flag = lane & 1; // even lanes extend to the left, odd lanes to the right (gapped_extension.cpp:33-48)
+  const int flag = kOneDir ? 1 : lane & 1; // even lanes extend to the left, odd lanes to the right (gapped_extension.cpp:33-48)
   const bool f0 = flag == 0;
   const int drop = a.o.drop_w_gap, min_helix = a.o.min_helix, delta = a.o.delta;
   const int64_t nwaves = (int64_t)gridDim.x * kFWaves;
-  constexpr int kTileHits = kFDirs / 2;
+  constexpr int kTileHits = kOneDir ? kFDirs : kFDirs / 2;
   const int64_t ntiles = (a.n + kTileHits - 1) / kTileHits;
   const bool isdir = lane < kFDirs; // (the lanes beyond the directions only take part in the pooled phases)
   const int me = isdir ? lane : 0;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
     unsigned long long nt = 0;
     if (lane == 0) nt = atomicAdd(a.next_work, 1ull);
     // ---- the hit, the direction's origin (:88-128) ----
-    const int64_t w = tile * kTileHits + (lane >> 1);
+    const int64_t w = tile * kTileHits + (kOneDir ? lane : lane >> 1);
     const bool live = isdir && w < a.n;
     int64_t x = 0, qo = 0, dbase = 0;
     int query = 0, id = 0, qn = 1, q_sp = 0, db_sp = 0, q_len = 0, db_len = 0, id_start = 0;
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
     const int64_t db_start = f0 ? (int64_t)db_sp : (int64_t)db_sp + US(db_len) - 1;
     const int id_end = id_start + US(db_len) - 1;
     bool dead = !live || (resumed && f0); // the direction is out of the proof: not there, done already, improved, or too many cells
+    if (kOneDir && !resumed) dead = true;  // (not what the list was promised to hold: the whole hit is the cascade's)
     FP_MARK(1);
 
     // ---- bases along both strands (:131-154 and GetChar) ----
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
         const uint32_t cell = has ? S.cells[c0 + lane] : 0u;
         const int dl = cell & 63, ci = (cell >> 8) & 31, isB = (cell >> 13) & 1, rec = (int)(cell >> 16);
         const int cj = LA + isB - ci;
-        const bool cf0 = (dl & 1) == 0;
+        const bool cf0 = !kOneDir && (dl & 1) == 0;
         // the direction's strands and list length, from its lane
         const uint32_t cq_lo = __shfl(q.lo, dl), cq_hi = __shfl(q.hi, dl), cq_v = __shfl(q.valid, dl);
         const uint32_t cd_lo = __shfl(dr.lo, dl), cd_hi = __shfl(dr.hi, dl), cd_v = __shfl(dr.valid, dl);
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
             const int k = cdv >> 25;
             const int pci = cdv & 31, pcj = (cdv >> 5) & 31, pct = (cdv >> 10) & 7, pnq = (cdv >> 13) & 7, pnd = (cdv >> 16) & 7,
                       pdl = (cdv >> 19) & 63;
-            const bool pf0 = (pdl & 1) == 0;
+            const bool pf0 = !kOneDir && (pdl & 1) == 0;
             const uint32_t v = S.info[k][pdl];
             const double hk = S.hyb[FRec::pool(v)]; // (needed last: the read is under way while the loop energy is looked up)
             const int ri = FRec::i(v), rj = FRec::j(v), rq = FRec::qa(v), rd = FRec::da(v), rt = FRec::type(v);
@@ -564,16 +568,26 @@ __global__ __launch_bounds__(64 * kFWaves) void k_gapped_front(GapArgs a, FrontA
     FP_COUNT(26, pool_used);
     FP_MARK(11);
     // ---- the hit: done when neither direction finds anything (GappedExtension::Run tail, :49-67) ----
-    const bool ok = live && (!dead || (resumed && f0));
-    const bool ok_other = __shfl_xor(ok ? 1 : 0, 1) != 0;
-    double dng = 0;
-    if (live) {
-      const int qp = f0 ? q_sp : q_sp + US(q_len) - 1;
-      const int64_t dp = f0 ? (int64_t)db_sp : (int64_t)db_sp + US(db_len) - 1;
-      dng = dangle_energy_gapped(sc, qp, dp, flag, qs, qn, a.pg.seqs, a.pg.nchars);
+    bool ok = live && (!dead || (resumed && f0));
+    bool ok_other;
+    double dng = 0, dng_other = 0; // of the hit's first / second end, as the lane that writes the hit sees them
+    if constexpr (kOneDir) {
+      ok_other = ok;  // the second direction: this lane's
+      ok = live && resumed; // the first one: done before
+      if (live) {
+        dng = dangle_energy_gapped(sc, q_sp, (int64_t)db_sp, 0, qs, qn, a.pg.seqs, a.pg.nchars);
+        dng_other = dangle_energy_gapped(sc, q_sp + US(q_len) - 1, (int64_t)db_sp + US(db_len) - 1, 1, qs, qn, a.pg.seqs, a.pg.nchars);
+      }
+    } else {
+      ok_other = __shfl_xor(ok ? 1 : 0, 1) != 0;
+      if (live) {
+        const int qp = f0 ? q_sp : q_sp + US(q_len) - 1;
+        const int64_t dp = f0 ? (int64_t)db_sp : (int64_t)db_sp + US(db_len) - 1;
+        dng = dangle_energy_gapped(sc, qp, dp, flag, qs, qn, a.pg.seqs, a.pg.nchars);
+      }
+      dng_other = __shfl_xor(dng, 1);
     }
-    const double dng_other = __shfl_xor(dng, 1);
-    if (live && f0) {
+    if (live && (kOneDir || f0)) {
       if (ok && ok_other) {
         const double d0 = dng, d1 = dng_other;
         double e = e_tot, hy = e_tot - e_acc;
@@ -652,14 +666,16 @@ size_t gapped_front_scratch_bytes() { return (size_t)256 * front_blocks_per_cu()
 
 hipError_t launch_gapped_front(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                                const SearchConst &sc, ExtOpts o, int tier_id, uint8_t *overflow, uint8_t *tier_out, int32_t *bp_count,
-                               unsigned long long *next_work, void *scratch, hipStream_t s) {
+                               unsigned long long *next_work, void *scratch, hipStream_t s, bool second_only) {
   if (n <= 0) return hipSuccess;
   GapArgs a{in,      out,     n,       subset,    qb, pg, sc, o, overflow, tier_out, tier_id, nullptr, bp_count,
             nullptr, nullptr, nullptr, next_work, GapResume{nullptr, nullptr, nullptr, 0}, GapResume{nullptr, nullptr, nullptr, 0}};
   if (hipError_t e = hipMemsetAsync(next_work, 0, sizeof(unsigned long long), s); e != hipSuccess) return e;
-  const int64_t tiles = (n + kFDirs / 2 - 1) / (kFDirs / 2), want_blocks = (tiles + kFWaves - 1) / kFWaves;
+  const int per_tile = second_only ? kFDirs : kFDirs / 2;
+  const int64_t tiles = (n + per_tile - 1) / per_tile, want_blocks = (tiles + kFWaves - 1) / kFWaves;
   const dim3 grid((unsigned)std::min<int64_t>(want_blocks, 256 * front_blocks_per_cu())), blk(64 * kFWaves);
-  hipLaunchKernelGGL(k_gapped_front, grid, blk, 0, s, a, static_cast<FrontAcc *>(scratch));
+  if (second_only) hipLaunchKernelGGL(k_gapped_front<true>, grid, blk, 0, s, a, static_cast<FrontAcc *>(scratch));
+  else hipLaunchKernelGGL(k_gapped_front<false>, grid, blk, 0, s, a, static_cast<FrontAcc *>(scratch));
   return hipGetLastError();
 }
 

@@ -254,7 +254,8 @@ bool gapped_front_supported(const SearchConst &sc, const ExtOpts &o);
 size_t gapped_front_scratch_bytes(); // HBM scratch of a launch (accessibility sums of the resident wavefronts; stays in L2)
 hipError_t launch_gapped_front(const HitSoA &in, HitSoA out, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                                const SearchConst &sc, ExtOpts o, int tier_id, uint8_t *overflow, uint8_t *tier_out, int32_t *bp_count,
-                               unsigned long long *next_work, void *scratch, hipStream_t s);
+                               unsigned long long *next_work, void *scratch, hipStream_t s,
+                               bool second_only = false /* every hit of the list has its first direction done (a resume / hand-over mark) */);
 hipError_t launch_bp_expand(const HitSoA &in, int64_t n, const uint32_t *subset, const QBatchDev &qb, const PageDev &pg,
                             const SearchConst &sc, const uint8_t *first_flag, const int32_t *ntrace, const uint8_t *tier_of,
                             const uint16_t *trace, const LongTrace &lt, const int64_t *bp_off, int32_t *bp_out, hipStream_t s);

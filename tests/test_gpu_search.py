@@ -163,7 +163,7 @@ def test_db_build_matches_reference_files(ctx, golden_dir, tmp_path):
 @pytest.mark.parametrize("env", ["PRB_GAPPED_FIRST_TIER=4", "PRB_GAPPED_FIRST_TIER=3", "PRB_GAPPED_FIRST_TIER=2",
                                  "PRB_GAPPED_FIRST_TIER=1", "PRB_TRACE_NO_SLOTS", "PRB_TRACE_SLOT_CAP", "PRB_SORT_FOUR_KEYS",
                                  "PRB_GAPPED_NO_RESUME", "PRB_GAPPED_HANDOVER=0", "PRB_GAPPED_HANDOVER=0,PRB_GAPPED_NO_RESUME", "PRB_GAPPED_RESUME_CAP", "PRB_GAPPED_CHUNK_HITS=37", "PRB_GAPPED_CHUNK_HITS=500,PRB_TRACE_SLOT_CAP=1", "PRB_GAPPED_FRONT=0", "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=1", "PRB_SEED_FUSED=0", "PRB_SEED_ROW_SHIFT=-1",
-                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS", "PRB_FILTER_TILES=0", "PRB_BIG_LIST_BYTES=1", "PRB_TRACE_NO_LONG", "PRB_GAPPED_FIRST_TIER=4,PRB_TRACE_NO_LONG",
+                                 "PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_WAVE_HBM=1", "PRB_GAPPED_PAIR=0", "PRB_SORT_TWO_LENGTHS", "PRB_FILTER_TILES=0", "PRB_BIG_LIST_BYTES=1", "PRB_GAPPED_FRONT_PAIRED", "PRB_TRACE_NO_LONG", "PRB_GAPPED_FIRST_TIER=4,PRB_TRACE_NO_LONG",
                                  "PRB_GAPPED_FIRST_TIER=4,PRB_TRACE_LONG_CAP=2", "PRB_GAPPED_FIRST_TIER=3,PRB_TRACE_LONG_CAP=1",
                                  "PRB_GAPPED_FRONT=0,PRB_GAPPED_FIRST_TIER=4,PRB_GAPPED_CHUNK_HITS=300",
                                  "PRB_BIG_LIST_BYTES=1,PRB_GAPPED_CHUNK_HITS=500,PRB_SEARCH_CHUNK_PAIRS=20000"])
