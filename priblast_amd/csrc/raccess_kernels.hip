@@ -45,9 +45,14 @@ __device__ unsigned long long g_ra_prof[32];
 #endif
 
 constexpr int kWave = 64;
-constexpr int kRaAhead = 8; // interior-loop terms fetched ahead of the fold in k_inside / k_outside
+#ifndef PRB_RA_AHEAD // (throughput-mode experiments: terms fetched ahead, wavefronts per workgroup, wavefronts per SIMD asked of the compiler)
+#define PRB_RA_AHEAD 8
+#define PRB_RA_WPB 4
+#define PRB_RA_WPS 3
+#endif
+constexpr int kRaAhead = PRB_RA_AHEAD; // interior-loop terms fetched ahead of the fold in k_inside / k_outside
 constexpr int kHB = 8;      // ... per batch when helper wavefronts prepare them (a barrier per batch: fewer, longer rounds)
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = PRB_RA_WPB;
 constexpr int kBlock = kWave * kWavesPerBlock;
 
 // band table ids inside one sequence's workspace block
@@ -209,7 +214,7 @@ __global__ void k_fill(double *p, int64_t n, double value) {
 // of it: phase 1, a barrier, then the fold (helpers -> folding wavefront, LDS counters) BESIDE phases 2 + 3, a barrier, the
 // last term.  A column costs phase 1 + the longer of the two instead of their sum.
 template <int NP, int kH>
-__global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_inside(RaBatch b, RaConst c) {
+__global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : PRB_RA_WPS) void k_inside(RaBatch b, RaConst c) {
   constexpr bool kF = kH == 3;
   __shared__ RaLds lds;
   __shared__ RowMasks rowmasks[kH ? 1 : kWavesPerBlock];
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_
 // kH = 3: phase A, a barrier, then the big fold of phase E (helpers -> folding wavefront) beside phases B - D on the
 // sequence's own wavefront, a barrier, the last two terms of phase E (they need Beta_multi2 of phase D) - see k_inside.
 template <int NP, int kH>
-__global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : 3) void k_outside(RaBatch b, RaConst c) {
+__global__ __launch_bounds__(kH ? kWave * (1 + kH) : kBlock, kH ? 1 : PRB_RA_WPS) void k_outside(RaBatch b, RaConst c) {
   constexpr bool kF = kH == 3;
   __shared__ RaLds lds;
   __shared__ RowMasks rowmasks[kH ? 1 : kWavesPerBlock];
