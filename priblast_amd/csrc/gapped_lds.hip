@@ -294,6 +294,18 @@ template <int G> __device__ __forceinline__ void group_min(double &te, int &key)
     if (G == 16) k = min(k, dpp_i32<0x140>(k));
     te = m;
     key = k;
+  } else if (G == 64) {
+    // rows of 16 lanes on the VALU (DPP), then the four rows through two exchanges: a third of the LDS-routed shuffles
+    group_min<16>(te, key);
+#pragma unroll
+    for (int m = 16; m <= 32; m <<= 1) {
+      const double ote = __shfl_xor(te, m);
+      const int ok = __shfl_xor(key, m);
+      if (ote < te || (ote == te && ok < key)) {
+        te = ote;
+        key = ok;
+      }
+    }
   } else {
 #pragma unroll
     for (int m = G / 2; m >= 1; m >>= 1) {
@@ -710,6 +722,79 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
     return ptype;
   };
 
+  // A wavefront per hit (tier 3, the wavefront-per-hit kernel): up to FOUR filled cells of the chunk at once, 16 lanes each -
+  // the cells of an anti-diagonal never see each other (fill_cell) -: each row of 16 scans the live candidates for its cell
+  // and reduces on the VALU (DPP); records and the running minimum then take the cells in their order.  A hit this long has
+  // ~5 cells per anti-diagonal and ~100 live candidates: the scan rounds are the same in number, the per-cell reduction over 64
+  // lanes (LDS-routed shuffles) and the per-cell bookkeeping are shared by four.
+  // `cellbits`: the filled cells of the chunk still to do (bit b: cell i0 + b), n = 2..4 of them are taken.
+  auto fill_quad = [&](int i0, unsigned long long cellbits, int n, unsigned long long tb0, unsigned long long tb1, unsigned long long tb2) {
+    GP_COUNT(12);
+    const int sub = gl >> 4, sl = gl & 15;
+    // the sub-th set bit of cellbits
+    unsigned long long mbits = cellbits;
+    for (int t = 0; t < sub; t++) mbits &= mbits - 1;
+    const bool act = sub < n;
+    const int b = act ? __builtin_ctzll(mbits) : __builtin_ctzll(cellbits);
+    const int ci = i0 + b, cj = d.length - ci;
+    const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) | (int)(((tb2 >> (gbase + b)) & 1) << 2);
+    const int nq = S.qb(ci - 1), nd = S.db(cj - 1);
+    const double eq_c = S.eq(ci - 1), ed_c = S.ed(cj - 1);
+    const int fq = S.qb(ci + 1), fd = S.db(cj + 1);
+    double bte = 1000000.0; // INF
+    int bkp = d.lo << 3;
+    for (int k0 = d.lo; k0 < dstart; k0 += 16) {
+      GP_COUNT(13);
+      const int k = k0 + sl;
+      if (k < dstart) {
+        const auto v = S.info(k);
+        const double hk = S.hyb(k);
+        const int ri = R::i(v), rj = R::j(v);
+        if (ri < ci && rj < cj) {
+          const int rq = R::kBases ? R::qa(v) : (int)S.qb(ri + 1), rd = R::kBases ? R::da(v) : (int)S.db(rj + 1);
+          const bool f0 = flag == 0;
+          const int rt = R::type(v);
+          double te = loop_energy_abcd(sc, f0 ? ctype : rt, f0 ? rt : ctype, ci - ri - 1, cj - rj - 1, f0 ? nq : rq, f0 ? nd : rd,
+                                       f0 ? rq : nq, f0 ? rd : nd);
+          te += hk;
+          if (te < bte) {
+            bte = te;
+            bkp = (k << 3) | R::type(v);
+          }
+        }
+      }
+    }
+    GP_MARK(4);
+    group_min<16>(bte, bkp);
+    GP_MARK(5);
+    int bk = bkp >> 3, ptype = bkp & 7;
+    if (d.lo >= dstart) bk = 0;
+    if (ptype == 0) ptype = R::type(S.info(bk));
+    if (act && sl == 0) {
+      const int rec = d.nrec + sub;
+      S.hyb(rec) = bte;
+      S.info(rec) = R::pack(ci, cj, bk, rtype_of(ctype), fq, fd);
+      S.ptab(cur, ci) = (uint8_t)ptype;
+    }
+    const double ie = eq_c + ed_c + bte;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { // the running minimum, cell by cell (:260-278)
+      if (t < n) {
+        const int l16 = 16 * t;
+        const double ie_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ie), l16), __builtin_amdgcn_readlane(__double2loint(ie), l16));
+        const int ci_t = __builtin_amdgcn_readlane(ci, l16);
+        if (ie_t < d.min_e) {
+          d.min_e = ie_t;
+          d.best = d.nrec + t;
+          d.min_ci = ci_t;
+          d.min_cj = d.length - ci_t;
+        }
+      }
+    }
+    d.nrec += n;
+    GP_MARK(6);
+  };
+
   // CheckHelixLength (:342-364) with GetBPType (:321-338) for cell (i, d.length - i) on the staged
   // bases, without branches (every lane of the wavefront walks through it anyway): pairs and wobble
   // pairs are bits of two 25-bit masks indexed by 5 * query base + database base; the pair type is
@@ -808,6 +893,14 @@ __device__ __forceinline__ bool dir_step(const SearchConst &sc, const SeqBases &
         break;
       }
       while (vmask) { // filled cells of this chunk, ascending i
+        if constexpr (G == 64) {
+          const int left = __popcll((unsigned long long)vmask), n = left < 4 ? left : 4;
+          if (n >= 2 && d.nrec + n <= S.cap_r()) {
+            fill_quad(i0, (unsigned long long)vmask, n, tb0, tb1, tb2);
+            for (int t = 0; t < n; t++) vmask &= vmask - 1;
+            continue;
+          }
+        }
         const int b = G <= 32 ? __builtin_ctz((uint32_t)vmask) : __builtin_ctzll((unsigned long long)vmask);
         vmask &= vmask - 1;
         const int ctype = (int)((tb0 >> (gbase + b)) & 1) | (int)(((tb1 >> (gbase + b)) & 1) << 1) |
